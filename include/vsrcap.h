@@ -1,0 +1,134 @@
+/*
+ * vsrcap.h - C ABI of the MI355X-native VSR-guided captioning decoder (libvsrcap.so).
+ *
+ * This is the drop-in boundary UNDER the reference's Python class
+ *   models.ControllableCaptioningModel   (/root/reference/models/controllable_captioning.py:10)
+ * and its decode / train loops            (/root/reference/models/CaptioningModel.py:22-294).
+ * The reference has no native ABI of its own (it is 100 % Python on ATen); each entry point below names
+ * the reference method it replaces.  The host-side mirror that keeps the reference's Python signatures
+ * lives in vsr-guided-cic_amd/models/ and binds these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name says host_; tensors are dense row-major fp32 /
+ *     int64 / int32 exactly as the reference lays them out (weights: [out, in]).
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); no call synchronises the host.
+ *   - the library allocates nothing on the launch path: the caller provides one workspace of
+ *     vsr_workspace_bytes() bytes (16-byte aligned) that must stay untouched between vsr_prepare() and
+ *     the decode / forward calls that use it.
+ *   - return value 0 = ok, non-zero = error; vsr_last_error() returns a thread-local message.
+ *   - one handle per device, not re-entrant per handle.
+ */
+#ifndef VSRCAP_H
+#define VSRCAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSR_ABI_VERSION 1
+#define VSR_MAX_BEAM 8
+
+/* ctor arguments of ControllableCaptioningModel (controllable_captioning.py:11-12) */
+typedef struct vsr_dims {
+    int32_t seq_len;              /* T  */
+    int32_t vocab_size;           /* V  */
+    int32_t bos_idx;
+    int32_t det_feat_size;        /* D  (multiple of 4) */
+    int32_t input_encoding_size;  /* E  (multiple of 4) */
+    int32_t rnn_size;             /* H  (multiple of 4) */
+    int32_t att_size;             /* A  (multiple of 4) */
+    int32_t h2_first_lstm;        /* 1: LSTM1 input is [h2 | vbar | x]   (:36-39)  */
+    int32_t img_second_lstm;      /* 1: LSTM2 input is [h1 | att | vbar] (:54-57)  */
+} vsr_dims;
+
+/* the 28 state_dict tensors, borrowed (no copy: optimizer updates stay visible); layout per
+ * controllable_captioning.py:23-68, row-major [out, in] */
+typedef struct vsr_weights {
+    const float* embed_weight;          /* (V, E) */
+    const float* W1_is_weight;          /* (H, in1)   in1 = [H +] D + E */
+    const float* W1_is_bias;            /* (H) */
+    const float* W1_hs_weight;          /* (H, H) */
+    const float* W1_hs_bias;
+    const float* att_va_weight;         /* (A, D) */
+    const float* att_ha_weight;         /* (A, H) */
+    const float* att_a_weight;          /* (1, A) */
+    const float* att_sa_weight;         /* (A, H) */
+    const float* att_s_weight;          /* (1, A) */
+    const float* lstm1_weight_ih;       /* (4H, in1)  gate order i,f,g,o */
+    const float* lstm1_weight_hh;       /* (4H, H) */
+    const float* lstm1_bias_ih;         /* (4H) */
+    const float* lstm1_bias_hh;
+    const float* lstm2_weight_ih;       /* (4H, in2)  in2 = H + D [+ D] */
+    const float* lstm2_weight_hh;
+    const float* lstm2_bias_ih;
+    const float* lstm2_bias_hh;
+    const float* out_fc_weight;         /* (V, H) */
+    const float* out_fc_bias;           /* (V) */
+    const float* s_fc_weight;           /* (D, H) */
+    const float* s_fc_bias;             /* (D) */
+    const float* W1_ig_weight;          /* (H, in1) */
+    const float* W1_ig_bias;
+    const float* W1_hg_weight;          /* (H, H) */
+    const float* W1_hg_bias;
+    const float* att_ga_weight;         /* (A, H) */
+    const float* att_g_weight;          /* (1, A) */
+} vsr_weights;
+
+typedef struct vsr_handle vsr_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+int vsr_abi_version(void);
+const char* vsr_last_error(void);
+/* replaces ControllableCaptioningModel.__init__ shape bookkeeping (:11-70) */
+int vsr_create(const vsr_dims* dims, vsr_handle** out);
+void vsr_destroy(vsr_handle* h);
+int vsr_bind_weights(vsr_handle* h, const vsr_weights* w);
+/* verb_2_vob_all table of step_v (:25-34, :283-292) as CSR: ids of verb v are
+ * vocab_ids[row_ptr[v] .. row_ptr[v+1]); verbs >= n_verbs have no entry.  DEVICE pointers, borrowed. */
+int vsr_set_verb_table(vsr_handle* h, const int32_t* row_ptr, const int32_t* vocab_ids, int32_t n_verbs);
+
+/* ---- workspace ------------------------------------------------------------------------------------ */
+/* bytes needed for B images with L slots of R regions, R0 pooled regions, decoding with up to `beam`
+ * hypotheses per image (1 for greedy / sampling / teacher forcing). */
+size_t vsr_workspace_bytes(const vsr_handle* h, int32_t B, int32_t R0, int32_t L, int32_t R, int32_t beam);
+
+/* ---- hoisted per-image work (step :126-128 pooled descriptor, :161 att_va(regions), :159 row masks) - */
+/* det (B,R0,D); regions (B,L,R,D) = statics[1] for decoding or seqs[1] (L == T) for teacher forcing.
+ * Both tensors are borrowed until the last call that uses this prepare. */
+int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R0, const float* regions, int32_t L, int32_t R,
+                int32_t beam, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- decode loops --------------------------------------------------------------------------------- */
+/* verbs: (B,L) fp32 or NULL (-1 = no verb) -> step_v semantics; gt as in beam_search_v(..., gt=) */
+/* CaptioningModel.test (:38-52): words/gates (B,T) int64 */
+int vsr_greedy(vsr_handle* h, const float* verbs, int32_t gt, int64_t* words, int64_t* gates, void* stream);
+/* CaptioningModel.sample_rl (:54-76).  forced_words/gates (B,T) int64 or NULL: replay given samples instead
+ * of drawing (Philox4x32-10 keyed by seed, Gumbel-max).  lp_* (B,T) fp32 = log-prob of the sample. */
+int vsr_sample(vsr_handle* h, uint64_t seed, const int64_t* forced_words, const int64_t* forced_gates,
+               int64_t* words, int64_t* gates, float* lp_words, float* lp_gates, void* stream);
+/* CaptioningModel.beam_search / beam_search_v (:116-294): joint (word x gate) beam search.
+ * words/gates (B,out_size,T) int64; lp_* (B,out_size,T) fp32 (the reference's per-slot log-probs, quirk 2
+ * of SURVEY.md 8a); scores (B,out_size) fp32 final sequence log-probs, may be NULL. */
+int vsr_beam(vsr_handle* h, int32_t beam, int32_t out_size, int64_t eos_word, int64_t eos_gate, const float* verbs,
+             int32_t gt, int64_t* words, int64_t* gates, float* lp_words, float* lp_gates, float* scores, void* stream);
+
+/* ---- teacher forcing (CaptioningModel.forward :22-36) --------------------------------------------- */
+/* captions (B,T) int64; prepare() must have been called with regions = seqs[1] (B,T,R,D), beam = 1.
+ * logp_words (B,T,V), logp_gates (B,T,2). */
+int vsr_xe_forward(vsr_handle* h, const int64_t* captions, int32_t T, float* logp_words, float* logp_gates, void* stream);
+
+/* ---- single timestep (ControllableCaptioningModel.step / step_v :117-297), feedback mode ---------- */
+/* state in/out: h1,c1,h2,c2 (M,H) fp32 and slot (M) int64, M = B * rows_per_image (rows of one image
+ * adjacent).  prev_words/prev_gates (M) int64 or NULL at t == 0.  logp_words (M,V), logp_gates (M,2). */
+int vsr_step(vsr_handle* h, int32_t t, int32_t rows_per_image, const int64_t* prev_words, const int64_t* prev_gates,
+             const float* h1, const float* c1, const float* h2, const float* c2, const int64_t* slot,
+             float* h1_out, float* c1_out, float* h2_out, float* c2_out, int64_t* slot_out,
+             const float* verbs, int32_t gt, float* logp_words, float* logp_gates, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSRCAP_H */

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by running the REAL reference (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+The reference (/root/reference, PyTorch CPU fp32) is imported as-is; weights and inputs come from the
+closed-form generator vsrcap.synth, so a fixture holds only small OUTPUT arrays plus the generator
+parameters needed to rebuild its inputs.  Nothing of the reference's source is stored.
+
+Fixtures:
+  g1_xe_small / g1_xe_wide / g1_xe_full   forward log-probs, XE losses (train.py:106-110), grad norms
+  g2_greedy                               256 greedy samples: word/gate ids, slot trace, fp64 margins
+  g3_beam                                 beam-5 / out_size 1 on the same 256 samples + rescored totals
+  g3_beam_small                           beam 3 / out_size 2 on config 1 (shapes, returned log-probs)
+  g4_beam_v / g4_beam_v_small             verb-forced beam search, gt False / True
+  g5_sample                               sample_rl draws of the reference + its log-probs (replay)
+  g6_step                                 single step from a non-zero state, pointer at the clamp
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.join(ROOT, "vsr-guided-cic_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from vsrcap import synth  # noqa: E402
+import vsr_oracle as vo  # noqa: E402
+
+NV = 8          # verb ids 0..7 in the hand-made verb table
+BOS = 2
+
+
+def cfg_small():
+    return dict(V=50, B=4, R0=10, R=10, D=512, L=5, T=12, E=64, H=64, A=32)
+
+
+def cfg_wide():
+    return dict(V=50, B=4, R0=10, R=10, D=512, L=5, T=12, E=1000, H=1000, A=512)
+
+
+def cfg_full(B):
+    return dict(V=10000, B=B, R0=36, R=36, D=2048, L=10, T=20, E=1000, H=1000, A=512)
+
+
+def build_ref(c, gains=None, wseed=0):
+    from models import ControllableCaptioningModel
+    m = ControllableCaptioningModel(c["T"], c["V"], BOS, det_feat_size=c["D"], input_encoding_size=c["E"],
+                                    rnn_size=c["H"], att_size=c["A"])
+    w = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=wseed, gains=gains)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    return m, w
+
+
+def inputs(c, seed, train=False):
+    det = torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed))
+    L = c["T"] if train else c["L"]
+    ctrl = torch.from_numpy(synth.make_ctrl(c["B"], L, c["R"], c["D"], seed=seed + (1000 if train else 0)))
+    return det, ctrl
+
+
+def save(name, meta, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def xe_fixture(name, c, gains, seed):
+    m, w = build_ref(c, gains)
+    m.train()
+    det, ctrl_seq = inputs(c, seed, train=True)
+    caps = torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed))
+    gts = torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed))
+    out, gate = m((det,), (caps, ctrl_seq))
+    loss, lc, lg = vo.xe_loss(out, gate, caps, gts)           # train.py:106-110 arithmetic
+    loss.backward()
+    gnorm = {k: float(p.grad.double().norm()) for k, p in m.named_parameters()}
+    gsum = {k: float(p.grad.double().sum()) for k, p in m.named_parameters()}
+    tgt = out.detach()[:, :-1].gather(2, caps[:, 1:, None])[:, :, 0]
+    arrays = dict(gate=gate.detach().numpy(), out_at_target=tgt.numpy(),
+                  out_max=out.detach().max(-1)[0].numpy(), out_argmax=out.detach().argmax(-1).numpy().astype(np.int32),
+                  losses=np.array([loss.item(), lc.item(), lg.item()], dtype=np.float64),
+                  grad_norm=np.array([gnorm[k] for k in w], dtype=np.float64),
+                  grad_sum=np.array([gsum[k] for k in w], dtype=np.float64))
+    if c["V"] <= 64:
+        arrays["out"] = out.detach().numpy()
+    save(name, dict(cfg=c, gains=gains, seed=seed, wseed=0, bos=BOS, param_order=list(w.keys())), **arrays)
+
+
+def pick_seed_and_greedy(c):
+    """Search the input seed whose fp64 greedy trace has comfortable arg-max margins, so that any correct
+    fp32 implementation reproduces the tokens exactly (SURVEY.md section 7 'hard parts')."""
+    w = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=0)
+    o32 = vo.Oracle(w, c["T"], BOS, as_written=False)
+    o64 = vo.Oracle(w, c["T"], BOS, as_written=False, dtype=torch.float64)
+    for seed in range(11, 40):
+        det, ctrl = inputs(c, seed)
+        with torch.no_grad():
+            w64, g64, marg, ks, _ = o64.test(det.double(), ctrl.double(), return_trace=True)
+            w32, g32 = o32.test(det, ctrl)
+        mw, mg = marg[:, :, 0].min().item(), marg[:, :, 1].min().item()
+        same = bool((w64 == w32).all() and (g64 == g32).all())
+        print("seed %d: min word margin %.2e, min gate margin %.2e, fp32==fp64 %s" % (seed, mw, mg, same))
+        if mw >= 2e-4 and mg >= 2e-3 and same:
+            return seed, w, (w64, g64, marg, ks)
+    raise RuntimeError("no seed with comfortable margins")
+
+
+def main():
+    torch.manual_seed(0)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "datasets/coco"))
+    cS, cW = cfg_small(), cfg_wide()
+    tables = {"small": synth.make_verb_table(NV, cS["V"], seed=0), "full": synth.make_verb_table(NV, 10000, seed=0)}
+    os.chdir(tmp)
+
+    def set_table(which):
+        json.dump(tables[which], open("datasets/coco/verb_2_vob_all_refine.json", "w"))
+        json.dump({}, open("datasets/coco/verb_2_vob.json", "w"))
+
+    set_table("small")
+    mild = {k: 1.0 for k in synth.DEFAULT_GAINS}
+
+    # ---------------- G1: XE forward / loss / grads
+    xe_fixture("g1_xe_small", cS, mild, seed=3)
+    xe_fixture("g1_xe_wide", cW, mild, seed=3)
+    xe_fixture("g1_xe_hot_small", cS, None, seed=3)
+    t0 = time.time()
+    xe_fixture("g1_xe_full", cfg_full(8), mild, seed=3)
+    print("full XE fixture %.1fs" % (time.time() - t0))
+
+    # ---------------- G3-small / G4-small / G6 on config 1
+    m, w = build_ref(cS)
+    m.eval()
+    det, ctrl = inputs(cS, 5)
+    verbs = torch.from_numpy(synth.make_verbs(cS["B"], cS["L"], NV, seed=5, p=0.3))
+    with torch.no_grad():
+        gw, gg = m.test(det, ctrl)
+        (bw, bg), blp = m.beam_search((det, ctrl), [3, -1], 3, 2)
+        (b1w, b1g), _ = m.beam_search((det, ctrl), [3, -1], 5, 1)
+        v = {}
+        for gt in (False, True):
+            (vw, vg), _ = m.beam_search_v((det, ctrl, verbs), [3, -1], 5, 1, gt=gt)
+            v["words_gt%d" % gt] = vw.numpy().astype(np.int32)
+            v["gates_gt%d" % gt] = vg.numpy().astype(np.int8)
+    meta = dict(cfg=cS, seed=5, wseed=0, bos=BOS, eos=[3, -1], nv=NV, verb_p=0.3, verb_table=tables["small"])
+    save("g3_beam_small", meta, greedy_words=gw.numpy().astype(np.int32), greedy_gates=gg.numpy().astype(np.int8),
+         words_b3o2=bw.numpy().astype(np.int32), gates_b3o2=bg.numpy().astype(np.int8),
+         lpw_b3o2=blp[0].numpy(), lpg_b3o2=blp[1].numpy(),
+         words_b5=b1w.numpy().astype(np.int32), gates_b5=b1g.numpy().astype(np.int8))
+    save("g4_beam_v_small", meta, **v)
+
+    # G6: one feedback step from a non-zero state with the slot pointer at / beyond the clamp
+    B, H, L = cS["B"], cS["H"], cS["L"]
+    st = [torch.from_numpy((synth.hash_u01(B * H, 50 + i, 9).reshape(B, H) - 0.5).astype(np.float32)) for i in range(4)]
+    k0 = torch.tensor([0, L - 2, L - 1, L - 1])
+    prev = (torch.tensor([5, 7, 11, 13]), torch.tensor([1, 1, 1, 0]))
+    with torch.no_grad():
+        (lw, lg), (s1, s2, k1) = m.step(3, ((st[0], st[1]), (st[2], st[3]), k0), prev, (det, ctrl), None, mode="feedback")
+    save("g6_step", dict(cfg=cS, seed=5, wseed=0, bos=BOS, t=3, k0=k0.tolist(), prev_w=prev[0].tolist(), prev_g=prev[1].tolist()),
+         logp_w=lw.numpy(), logp_g=lg.numpy(), h1=s1[0].numpy(), c1=s1[1].numpy(), h2=s2[0].numpy(), c2=s2[1].numpy(),
+         k=k1.numpy())
+
+    # ---------------- G2: greedy, 256 samples, full size
+    set_table("full")
+    cF = cfg_full(256)
+    seed, w, (w64, g64, marg, ks) = pick_seed_and_greedy(cF)
+    m, _ = build_ref(cF)
+    m.eval()
+    det, ctrl = inputs(cF, seed)
+    t0 = time.time()
+    with torch.no_grad():
+        rw, rg = m.test(det, ctrl)
+    print("reference greedy 256: %.1fs" % (time.time() - t0))
+    assert (rw == w64).all() and (rg == g64).all(), "reference fp32 greedy != fp64 oracle greedy"
+    n_distinct = len(torch.unique(rw))
+    gate1 = rg.float().mean().item()
+    reach = int((ks[:, -1] == cF["L"] - 1).sum())
+    vals, counts = torch.unique(rw, return_counts=True)
+    eos = int(vals[counts.argmax()])           # the API takes eos as a parameter: use a token that occurs
+    print("distinct %d, gate-1 %.3f, rows reaching last slot %d, eos id %d (x%d)" % (n_distinct, gate1, reach, eos, counts.max()))
+    assert n_distinct >= 200 and 0.2 <= gate1 <= 0.8 and reach > 0
+    meta = dict(cfg=cF, seed=seed, wseed=0, bos=BOS, eos=[eos, -1])
+    save("g2_greedy", meta, words=rw.numpy().astype(np.int16), gates=rg.numpy().astype(np.int8),
+         slots=ks.numpy().astype(np.int8), margins=marg.numpy().astype(np.float32))
+
+    # ---------------- G3: beam-5 on the same samples
+    t0 = time.time()
+    with torch.no_grad():
+        (bw, bg), _ = m.beam_search((det, ctrl), [eos, -1], 5, 1)
+        (b1w, b1g), _ = m.beam_search((det[:16], ctrl[:16]), [eos, -1], 1, 1)
+    print("reference beam-5 256: %.1fs" % (time.time() - t0))
+    assert (b1w == rw[:16]).all() and (b1g == rg[:16]).all()       # beam 1 == greedy (quirk 3)
+    o64 = vo.Oracle(w, cF["T"], BOS, as_written=False, dtype=torch.float64)
+    with torch.no_grad():
+        (ow, og), _, sc = o64.beam_search(det.double(), ctrl.double(), [eos, -1], 5, 1, return_scores=True)
+    agree = ((ow == bw).all(1) & (og == bg).all(1))
+    print("beam: reference fp32 vs oracle fp64 rows equal: %d / 256" % int(agree.sum()))
+    save("g3_beam", meta, words=bw.numpy().astype(np.int16), gates=bg.numpy().astype(np.int8),
+         score64=sc[:, 0].numpy(), agree64=agree.numpy())
+
+    # ---------------- G4: verb-forced beam search, full size, 32 samples
+    verbs = torch.from_numpy(synth.make_verbs(32, cF["L"], NV, seed=seed, p=0.15))
+    v = {}
+    with torch.no_grad():
+        for gt in (False, True):
+            (vw, vg), _ = m.beam_search_v((det[:32], ctrl[:32], verbs), [eos, -1], 5, 1, gt=gt)
+            v["words_gt%d" % gt] = vw.numpy().astype(np.int16)
+            v["gates_gt%d" % gt] = vg.numpy().astype(np.int8)
+    save("g4_beam_v", dict(meta, nv=NV, verb_p=0.15, n=32, verb_table=tables["full"]), **v)
+
+    # ---------------- G5: sampling replay, 32 samples
+    torch.manual_seed(1234)
+    with torch.no_grad():
+        (sw, sg), (lw, lg) = m.sample_rl(det[:32], ctrl[:32])
+    save("g5_sample", dict(meta, n=32, torch_seed=1234), words=sw.numpy().astype(np.int16), gates=sg.numpy().astype(np.int8),
+         lp_w=lw.numpy(), lp_g=lg.numpy())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,271 @@
+"""GPU parity tests proper: the HIP path (through the reference-shaped Python class and the C ABI) against
+(1) golden vectors captured from the real reference and (2) the CPU oracle on the same seeded inputs.
+Token / gate / index results must be bit-exact; log-probs within the stated fp32 tolerances."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+LOGP_TOL = 2e-4      # absolute, on log-probs of magnitude up to ~60 (fp32 sums in a different order)
+DEV = "cuda"
+
+
+def _model_for(meta, gains=None, table=None, **kw):
+    cfg = meta["cfg"]
+    w = helpers.weights_for(cfg, gains=gains, wseed=meta.get("wseed", 0))
+    return helpers.build_model(cfg, w, DEV, bos=meta["bos"], verb_table=table, **kw), w
+
+
+# ------------------------------------------------------------------ config 1 (small) and wide: XE forward
+@pytest.mark.parametrize("name", ["g1_xe_small", "g1_xe_wide", "g1_xe_hot_small", "g1_xe_full"])
+def test_xe_forward_matches_reference(name):
+    meta, g = load_golden(name)
+    cfg = meta["cfg"]
+    m, _ = _model_for(meta, gains=meta["gains"])
+    det, ctrl_seq, caps, gts = helpers.train_inputs(cfg, meta["seed"])
+    with torch.no_grad():
+        out, gate = m((det.to(DEV),), (caps.to(DEV), ctrl_seq.to(DEV)))
+    out, gate = out.cpu(), gate.cpu()
+    assert out.shape == (cfg["B"], cfg["T"], cfg["V"]) and gate.shape == (cfg["B"], cfg["T"], 2)
+    tol = LOGP_TOL if "hot" in name else 2e-5
+    np.testing.assert_allclose(gate.numpy(), g["gate"], atol=tol, rtol=0)
+    tgt = out[:, :-1].gather(2, caps[:, 1:, None])[:, :, 0]
+    np.testing.assert_allclose(tgt.numpy(), g["out_at_target"], atol=tol, rtol=0)
+    np.testing.assert_allclose(out.max(-1)[0].numpy(), g["out_max"], atol=tol, rtol=0)
+    if "out" in g:
+        np.testing.assert_allclose(out.numpy(), g["out"], atol=tol, rtol=0)
+    # XE loss of coco_scripts/train.py:106-110 within 1e-4 of the reference (north star)
+    import vsr_oracle as vo
+    loss, lc, lg = vo.xe_loss(out, gate, caps, gts)
+    if "hot" not in name:
+        assert abs(loss.item() - g["losses"][0]) < 1e-4, (loss.item(), g["losses"])
+        assert abs(lc.item() - g["losses"][1]) < 1e-4 and abs(lg.item() - g["losses"][2]) < 1e-4
+
+
+# ------------------------------------------------------------------ config 1: decode loops
+def test_small_greedy_beam_and_verbs():
+    meta, g = load_golden("g3_beam_small")
+    _, gv = load_golden("g4_beam_v_small")
+    cfg = meta["cfg"]
+    m, _ = _model_for(meta, table=meta["verb_table"])
+    det, ctrl = helpers.decode_inputs(cfg, meta["seed"])
+    det, ctrl = det.to(DEV), ctrl.to(DEV)
+    with torch.no_grad():
+        w, gt_ = m.test(det, ctrl)
+        assert w.dtype == torch.int64 and w.shape == (cfg["B"], cfg["T"])
+        np.testing.assert_array_equal(w.cpu().numpy(), g["greedy_words"])
+        np.testing.assert_array_equal(gt_.cpu().numpy(), g["greedy_gates"])
+        (bw, bg), (lw, lg) = m.beam_search((det, ctrl), meta["eos"], 3, 2)
+        assert bw.shape == (cfg["B"], 2, cfg["T"]) and lw.shape == (cfg["B"], 2, cfg["T"])
+        np.testing.assert_array_equal(bw.cpu().numpy(), g["words_b3o2"])
+        np.testing.assert_array_equal(bg.cpu().numpy(), g["gates_b3o2"])
+        np.testing.assert_allclose(lw.cpu().numpy(), g["lpw_b3o2"], atol=LOGP_TOL, rtol=0)
+        np.testing.assert_allclose(lg.cpu().numpy(), g["lpg_b3o2"], atol=LOGP_TOL, rtol=0)
+        (bw, bg), _ = m.beam_search((det, ctrl), meta["eos"], 5, 1)
+        assert bw.shape == (cfg["B"], cfg["T"])
+        np.testing.assert_array_equal(bw.cpu().numpy(), g["words_b5"])
+        np.testing.assert_array_equal(bg.cpu().numpy(), g["gates_b5"])
+        # beam 1 == greedy
+        (b1w, b1g), _ = m.beam_search((det, ctrl), meta["eos"], 1, 1)
+        np.testing.assert_array_equal(b1w.cpu().numpy(), g["greedy_words"])
+        np.testing.assert_array_equal(b1g.cpu().numpy(), g["greedy_gates"])
+        from vsrcap import synth
+        verbs = torch.from_numpy(synth.make_verbs(cfg["B"], cfg["L"], meta["nv"], seed=meta["seed"], p=meta["verb_p"]))
+        for flag in (False, True):
+            (vw, vg), _ = m.beam_search_v((det, ctrl, verbs.to(DEV)), meta["eos"], 5, 1, gt=flag)
+            np.testing.assert_array_equal(vw.cpu().numpy(), gv["words_gt%d" % flag])
+            np.testing.assert_array_equal(vg.cpu().numpy(), gv["gates_gt%d" % flag])
+
+
+def test_single_step_from_nonzero_state():
+    meta, g = load_golden("g6_step")
+    cfg = meta["cfg"]
+    m, _ = _model_for(meta)
+    from vsrcap import synth
+    det, ctrl = helpers.decode_inputs(cfg, meta["seed"])
+    B, H = cfg["B"], cfg["H"]
+    st = [torch.from_numpy((synth.hash_u01(B * H, 50 + i, 9).reshape(B, H) - 0.5).astype(np.float32)).to(DEV) for i in range(4)]
+    k0 = torch.tensor(meta["k0"], device=DEV)
+    prev = (torch.tensor(meta["prev_w"], device=DEV), torch.tensor(meta["prev_g"], device=DEV))
+    with torch.no_grad():
+        (lw, lg), (s1, s2, k1) = m.step(meta["t"], ((st[0], st[1]), (st[2], st[3]), k0), prev, (det.to(DEV), ctrl.to(DEV)), None,
+                                        mode="feedback")
+    np.testing.assert_array_equal(k1.cpu().numpy(), g["k"])
+    np.testing.assert_allclose(lw.cpu().numpy(), g["logp_w"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(lg.cpu().numpy(), g["logp_g"], atol=2e-5, rtol=0)
+    for got, key in ((s1[0], "h1"), (s1[1], "c1"), (s2[0], "h2"), (s2[1], "c2")):
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], atol=2e-6, rtol=0)
+
+
+# ------------------------------------------------------------------ full size: greedy token-id parity on 256 samples
+@pytest.fixture(scope="module")
+def full_model():
+    meta, _ = load_golden("g2_greedy")
+    _, g4 = load_golden("g4_beam_v")
+    meta4, _ = load_golden("g4_beam_v")
+    m, w = _model_for(meta, table=meta4["verb_table"])
+    det, ctrl = helpers.decode_inputs(meta["cfg"], meta["seed"])
+    return meta, m, w, det.to(DEV), ctrl.to(DEV)
+
+
+def test_greedy_256_token_for_token(full_model):
+    meta, m, _, det, ctrl = full_model
+    _, g = load_golden("g2_greedy")
+    with torch.no_grad():
+        w, gate = m.test(det, ctrl)
+    np.testing.assert_array_equal(w.cpu().numpy(), g["words"].astype(np.int64))
+    np.testing.assert_array_equal(gate.cpu().numpy(), g["gates"].astype(np.int64))
+    # batch-100 slice (BASELINE config 2) decodes identically on its own
+    with torch.no_grad():
+        w100, g100 = m.test(det[:100].contiguous(), ctrl[:100].contiguous())
+    np.testing.assert_array_equal(w100.cpu().numpy(), g["words"][:100].astype(np.int64))
+    np.testing.assert_array_equal(g100.cpu().numpy(), g["gates"][:100].astype(np.int64))
+
+
+def test_beam5_256_matches_reference(full_model):
+    meta, m, _, det, ctrl = full_model
+    _, g = load_golden("g3_beam")
+    with torch.no_grad():
+        (w, gate), _ = m.beam_search((det, ctrl), meta["eos"], 5, 1)
+    w, gate = w.cpu().numpy(), gate.cpu().numpy()
+    same = (w == g["words"]).all(1) & (gate == g["gates"]).all(1)
+    # rows where the reference (fp32) and the fp64 oracle agree are numerically well separated: exact there
+    solid = g["agree64"].astype(bool)
+    assert same[solid].all(), "beam-5 mismatch on rows %s" % np.nonzero(~same & solid)[0][:10]
+    assert same.mean() >= 0.99
+    # beam 1 == greedy on the device too
+    _, gg = load_golden("g2_greedy")
+    with torch.no_grad():
+        (w1, g1), _ = m.beam_search((det[:64].contiguous(), ctrl[:64].contiguous()), meta["eos"], 1, 1)
+    np.testing.assert_array_equal(w1.cpu().numpy(), gg["words"][:64].astype(np.int64))
+
+
+def test_beam_v_full(full_model):
+    meta, m, _, det, ctrl = full_model
+    meta4, g = load_golden("g4_beam_v")
+    from vsrcap import synth
+    n = meta4["n"]
+    verbs = torch.from_numpy(synth.make_verbs(n, meta["cfg"]["L"], meta4["nv"], seed=meta["seed"], p=meta4["verb_p"])).to(DEV)
+    for flag in (False, True):
+        with torch.no_grad():
+            (w, gate), _ = m.beam_search_v((det[:n].contiguous(), ctrl[:n].contiguous(), verbs), meta["eos"], 5, 1, gt=flag)
+        np.testing.assert_array_equal(w.cpu().numpy(), g["words_gt%d" % flag].astype(np.int64))
+        np.testing.assert_array_equal(gate.cpu().numpy(), g["gates_gt%d" % flag].astype(np.int64))
+
+
+def test_sample_replay_and_distribution(full_model):
+    meta, m, w, det, ctrl = full_model
+    meta5, g = load_golden("g5_sample")
+    n = meta5["n"]
+    fw, fg = torch.from_numpy(g["words"].astype(np.int64)), torch.from_numpy(g["gates"].astype(np.int64))
+    d, c = det[:n].contiguous(), ctrl[:n].contiguous()
+    with torch.no_grad():
+        (sw, sg), (lw, lg) = m.sample_rl(d, c, forced=(fw, fg))
+    np.testing.assert_array_equal(sw.cpu().numpy(), fw.numpy())
+    np.testing.assert_allclose(lw.cpu().numpy(), g["lp_w"], atol=1e-4, rtol=0)      # north star: 1e-4 on replayed log-probs
+    np.testing.assert_allclose(lg.cpu().numpy(), g["lp_g"], atol=1e-4, rtol=0)
+    # the device sampler: reproducible per seed, different across seeds, log-probs consistent with a replay
+    with torch.no_grad():
+        (a_w, a_g), (a_lw, a_lg) = m.sample_rl(d, c, seed=7)
+        (b_w, b_g), _ = m.sample_rl(d, c, seed=7)
+        (c_w, _), _ = m.sample_rl(d, c, seed=8)
+        (_, _), (r_lw, r_lg) = m.sample_rl(d, c, forced=(a_w, a_g))
+    assert (a_w == b_w).all() and (a_g == b_g).all() and (a_w != c_w).any()
+    np.testing.assert_allclose(a_lw.cpu().numpy(), r_lw.cpu().numpy(), atol=1e-5, rtol=0)
+    np.testing.assert_allclose(a_lg.cpu().numpy(), r_lg.cpu().numpy(), atol=1e-5, rtol=0)
+
+
+def test_first_step_sampler_frequencies():
+    """chi-square of the Gumbel-max sampler against exp(logp) at t = 0 (all rows share the state)."""
+    meta, _ = load_golden("g3_beam_small")
+    cfg = dict(meta["cfg"])
+    m, w = _model_for(meta)
+    det, ctrl = helpers.decode_inputs(cfg, meta["seed"])
+    reps = 4096
+    d = det[:1].expand(reps, -1, -1).contiguous().to(DEV)
+    c = ctrl[:1].expand(reps, -1, -1, -1).contiguous().to(DEV)
+    with torch.no_grad():
+        (sw, sg), _ = m.sample_rl(d, c, seed=123)
+        st = m.init_state(1, DEV)
+        (lw, lg), _ = m.step(0, st, None, (det[:1].to(DEV), ctrl[:1].to(DEV)), None, mode="feedback")
+    p = lw[0].exp().cpu().numpy().astype(np.float64)
+    cnt = np.bincount(sw[:, 0].cpu().numpy(), minlength=cfg["V"]).astype(np.float64)
+    keep = p * reps >= 5
+    chi2 = (((cnt - p * reps) ** 2) / (p * reps))[keep].sum()
+    dof = keep.sum() - 1
+    assert chi2 < dof + 6 * np.sqrt(2 * dof) + 10, (chi2, dof)
+    pg = lg[0].exp().cpu().numpy()
+    f1 = sg[:, 0].float().mean().item()
+    assert abs(f1 - pg[1]) < 5 * np.sqrt(max(pg[1] * (1 - pg[1]), 1e-4) / reps) + 1e-3
+
+
+# ------------------------------------------------------------------ HIP path vs the CPU oracle on fresh seeds / edge cases
+@pytest.mark.parametrize("flags", [dict(h2_first_lstm=False), dict(img_second_lstm=True), dict()])
+def test_oracle_agreement_config_flags(flags):
+    import vsr_oracle as vo
+    cfg = dict(V=73, B=5, R0=7, R=9, D=256, L=4, T=9, E=48, H=80, A=24)
+    from vsrcap import synth
+    w = synth.make_weights(cfg["V"], cfg["D"], cfg["E"], cfg["H"], cfg["A"], seed=3, **flags)
+    m = helpers.build_model(cfg, w, DEV, **flags)
+    o = vo.Oracle(w, cfg["T"], 2, as_written=False, **flags)
+    det, ctrl = helpers.decode_inputs(cfg, 21)
+    det[2, 1:] = 0           # an image with a single valid pooled region
+    ctrl[1, 2] = 0           # a slot with NO valid region: attention collapses onto the sentinel
+    with torch.no_grad():
+        ow, og = o.test(det, ctrl)
+        w_, g_ = m.test(det.to(DEV), ctrl.to(DEV))
+        (obw, obg), _, osc = o.beam_search(det, ctrl, [3, -1], 4, 1, return_scores=True)
+        (bw, bg), _ = m.beam_search((det.to(DEV), ctrl.to(DEV)), [3, -1], 4, 1)
+    np.testing.assert_array_equal(w_.cpu().numpy(), ow.numpy())
+    np.testing.assert_array_equal(g_.cpu().numpy(), og.numpy())
+    np.testing.assert_array_equal(bw.cpu().numpy(), obw.numpy())
+    np.testing.assert_array_equal(bg.cpu().numpy(), obg.numpy())
+    _, ctrl_seq, caps, _ = helpers.train_inputs(cfg, 22)
+    with torch.no_grad():
+        oo, ogt = o.forward(det, caps, ctrl_seq)
+        out, gate = m((det.to(DEV),), (caps.to(DEV), ctrl_seq.to(DEV)))
+    np.testing.assert_allclose(out.cpu().numpy(), oo.numpy(), atol=LOGP_TOL, rtol=0)
+    np.testing.assert_allclose(gate.cpu().numpy(), ogt.numpy(), atol=LOGP_TOL, rtol=0)
+
+
+def test_ragged_batch_sizes_and_max_beam():
+    """B not a multiple of any tile, beam = VSR_MAX_BEAM, R+1 > 64 regions (softmax spans two wave passes)."""
+    import vsr_oracle as vo
+    from vsrcap import synth
+    cfg = dict(V=301, B=3, R0=5, R=70, D=64, L=3, T=6, E=32, H=36, A=16)
+    w = synth.make_weights(cfg["V"], cfg["D"], cfg["E"], cfg["H"], cfg["A"], seed=5)
+    m = helpers.build_model(cfg, w, DEV)
+    o = vo.Oracle(w, cfg["T"], 2, as_written=False)
+    det, ctrl = helpers.decode_inputs(cfg, 31)
+    with torch.no_grad():
+        (obw, obg), _ = o.beam_search(det, ctrl, [3, -1], 8, 3)
+        (bw, bg), _ = m.beam_search((det.to(DEV), ctrl.to(DEV)), [3, -1], 8, 3)
+    np.testing.assert_array_equal(bw.cpu().numpy(), obw.numpy())
+    np.testing.assert_array_equal(bg.cpu().numpy(), obg.numpy())
+    with pytest.raises(RuntimeError):
+        m.beam_search((det.to(DEV), ctrl.to(DEV)), [3, -1], 9, 1)      # beyond VSR_MAX_BEAM: loud error
+    with pytest.raises(RuntimeError):
+        m.test(det, ctrl)                                              # CPU tensors: no fallback
+
+
+def test_eos_on_both_streams_freezes_hypotheses():
+    """eos on BOTH streams exercises the freeze branch of beam_search (CaptioningModel.py:143-150)."""
+    import vsr_oracle as vo
+    meta, _ = load_golden("g3_beam_small")
+    cfg = meta["cfg"]
+    m, w = _model_for(meta)
+    o = vo.Oracle(w, cfg["T"], 2, as_written=False)
+    det, ctrl = helpers.decode_inputs(cfg, meta["seed"])
+    with torch.no_grad():
+        gw, gg = o.test(det, ctrl)
+    eos = [int(gw[0, 2]), int(gg[0, 2])]
+    with torch.no_grad():
+        (ow, og), olp, osc = o.beam_search(det, ctrl, eos, 3, 1, return_scores=True)
+        eng = m._engine(torch.device(DEV))
+        B = eng.prepare(det.to(DEV), ctrl.to(DEV), 3, m._weights_version())
+        (w_, g_), (lw, lg), sc = eng.beam(B, torch.device(DEV), 3, 1, eos[0], eos[1])
+    np.testing.assert_allclose(sc[:, 0].cpu().numpy(), osc[:, 0].numpy(), atol=1e-4, rtol=0)

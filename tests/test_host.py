@@ -1,0 +1,61 @@
+"""CPU checks of the host-side mirror: constructor, state_dict contract, loud failure without a GPU."""
+import pytest
+import torch
+
+import helpers
+from vsrcap import synth
+
+
+def test_state_dict_keys_and_shapes_match_reference_contract():
+    from models import ControllableCaptioningModel
+    for flags in (dict(), dict(h2_first_lstm=False), dict(img_second_lstm=True)):
+        m = ControllableCaptioningModel(20, 123, 2, det_feat_size=64, input_encoding_size=32, rnn_size=40, att_size=16,
+                                        verb_2_vob_all={}, **flags)
+        want = synth.param_shapes(123, 64, 32, 40, 16, **flags)
+        got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert list(got.keys()) == list(want.keys())
+        assert got == {k: tuple(v) for k, v in want.items()}
+    # zero biases, orthogonal recurrent weights (init_weights :72-107)
+    assert float(m.out_fc.bias.abs().sum()) == 0 and float(m.lstm_cell_1.bias_ih.abs().sum()) == 0
+    w = m.lstm_cell_1.weight_hh
+    assert torch.allclose(w.t() @ w, torch.eye(40), atol=1e-4)
+
+
+def test_default_size_parameter_count():
+    n = sum(int(torch.tensor(s).prod()) for s in synth.param_shapes(10000).values())
+    assert n == 71146160
+
+
+def test_ctor_reads_json_tables_from_cwd(tmp_path, monkeypatch):
+    from models import ControllableCaptioningModel
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(FileNotFoundError):
+        ControllableCaptioningModel(5, 20, 2, det_feat_size=8, input_encoding_size=8, rnn_size=8, att_size=8)
+    (tmp_path / "datasets" / "coco").mkdir(parents=True)
+    (tmp_path / "datasets" / "coco" / "verb_2_vob_all_refine.json").write_text('{"3": [4, 5]}')
+    (tmp_path / "datasets" / "coco" / "verb_2_vob.json").write_text('{}')
+    m = ControllableCaptioningModel(5, 20, 2, det_feat_size=8, input_encoding_size=8, rnn_size=8, att_size=8)
+    assert m.verb_2_vob_all == {"3": [4, 5]}
+
+
+def test_compute_on_cpu_fails_loudly():
+    cfg = dict(V=20, B=2, R0=3, R=3, D=8, L=2, T=4, E=8, H=8, A=8)
+    m = helpers.build_model(cfg, synth.make_weights(20, 8, 8, 8, 8), "cpu")
+    det, ctrl = helpers.decode_inputs(cfg, 1)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m.test(det, ctrl)
+    with pytest.raises(RuntimeError, match="GPU"):
+        m.beam_search((det, ctrl), [3, -1], 2, 1)
+    st = m.init_state(2, torch.device("cpu"))
+    assert st[0][0].shape == (2, 8) and st[2].dtype == torch.long
+
+
+def test_synth_is_deterministic_and_padded():
+    a = synth.make_ctrl(3, 4, 6, 16, seed=9)
+    b = synth.make_ctrl(3, 4, 6, 16, seed=9)
+    assert (a == b).all() and (a >= 0).all()
+    nz = (a.sum(-1) != 0)
+    assert nz[:, :, 0].all()                      # at least one valid row per slot
+    assert ((nz[:, :, 1:] <= nz[:, :, :-1])).all()  # valid rows first, zero padding after
+    d = synth.make_detections(5, 12, 16, seed=9)
+    assert ((d.sum(-1) != 0).sum(1) >= 1).all()

@@ -1,0 +1,154 @@
+"""Pin the CPU oracle to the golden vectors captured from the real reference (tests/golden/make_golden.py),
+and - when /root/reference is mounted (build container only) - to the reference run live."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+import helpers
+import vsr_oracle as vo
+from vsrcap import synth
+
+
+def _oracle(meta, gains=None, table=None, as_written=False, dtype=torch.float32):
+    cfg = meta["cfg"]
+    w = helpers.weights_for(cfg, gains=gains, wseed=meta.get("wseed", 0))
+    return vo.Oracle(w, cfg["T"], meta["bos"], verb_table=table, as_written=as_written, dtype=dtype), w
+
+
+@pytest.mark.parametrize("name", ["g1_xe_small", "g1_xe_wide", "g1_xe_hot_small"])
+@pytest.mark.parametrize("as_written", [True, False])
+def test_xe_forward_and_loss(name, as_written):
+    meta, g = load_golden(name)
+    cfg = meta["cfg"]
+    o, _ = _oracle(meta, gains=meta["gains"], as_written=as_written)
+    det, ctrl_seq, caps, gts = helpers.train_inputs(cfg, meta["seed"])
+    with torch.no_grad():
+        out, gate = o.forward(det, caps, ctrl_seq)
+    tol = 1e-4 if "hot" in name else 1e-5
+    np.testing.assert_allclose(gate.numpy(), g["gate"], atol=tol, rtol=0)
+    np.testing.assert_allclose(out.numpy(), g["out"], atol=tol, rtol=0)
+    loss, lc, lg = vo.xe_loss(out, gate, caps, gts)
+    np.testing.assert_allclose([loss.item(), lc.item(), lg.item()], g["losses"], atol=tol * 10, rtol=0)
+
+
+def test_xe_gradients_match_reference():
+    """autograd through the oracle reproduces the reference's per-parameter gradient norms (G1)."""
+    meta, g = load_golden("g1_xe_small")
+    cfg = meta["cfg"]
+    o, w = _oracle(meta, gains=meta["gains"])
+    for k in o.p:
+        o.p[k].requires_grad_(True)
+    det, ctrl_seq, caps, gts = helpers.train_inputs(cfg, meta["seed"])
+    out, gate = o.forward(det, caps, ctrl_seq)
+    vo.xe_loss(out, gate, caps, gts)[0].backward()
+    gn = np.array([float(o.p[k].grad.double().norm()) for k in meta["param_order"]])
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("as_written", [True, False])
+def test_small_decode_loops(as_written):
+    meta, g = load_golden("g3_beam_small")
+    _, gv = load_golden("g4_beam_v_small")
+    cfg = meta["cfg"]
+    o, _ = _oracle(meta, table=meta["verb_table"], as_written=as_written)
+    det, ctrl = helpers.decode_inputs(cfg, meta["seed"])
+    with torch.no_grad():
+        w, gt_ = o.test(det, ctrl)
+        np.testing.assert_array_equal(w.numpy(), g["greedy_words"])
+        np.testing.assert_array_equal(gt_.numpy(), g["greedy_gates"])
+        (bw, bg), (lw, lg) = o.beam_search(det, ctrl, meta["eos"], 3, 2)
+        np.testing.assert_array_equal(bw.numpy(), g["words_b3o2"])
+        np.testing.assert_array_equal(bg.numpy(), g["gates_b3o2"])
+        np.testing.assert_allclose(lw.numpy(), g["lpw_b3o2"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(lg.numpy(), g["lpg_b3o2"], atol=1e-4, rtol=0)
+        (bw, bg), _ = o.beam_search(det, ctrl, meta["eos"], 5, 1)
+        np.testing.assert_array_equal(bw.numpy(), g["words_b5"])
+        (b1, _), _ = o.beam_search(det, ctrl, meta["eos"], 1, 1)
+        np.testing.assert_array_equal(b1.numpy(), g["greedy_words"])
+        verbs = torch.from_numpy(synth.make_verbs(cfg["B"], cfg["L"], meta["nv"], seed=meta["seed"], p=meta["verb_p"]))
+        for flag in (False, True):
+            (vw, vg), _ = o.beam_search(det, ctrl, meta["eos"], 5, 1, verbs=verbs, gt=flag)
+            np.testing.assert_array_equal(vw.numpy(), gv["words_gt%d" % flag])
+            np.testing.assert_array_equal(vg.numpy(), gv["gates_gt%d" % flag])
+
+
+def test_single_step_vector():
+    meta, g = load_golden("g6_step")
+    cfg = meta["cfg"]
+    o, _ = _oracle(meta)
+    det, ctrl = helpers.decode_inputs(cfg, meta["seed"])
+    B, H = cfg["B"], cfg["H"]
+    st = [torch.from_numpy((synth.hash_u01(B * H, 50 + i, 9).reshape(B, H) - 0.5).astype(np.float32)) for i in range(4)]
+    state = st + [torch.tensor(meta["k0"])]
+    prev = (torch.tensor(meta["prev_w"]), torch.tensor(meta["prev_g"]))
+    with torch.no_grad():
+        (lw, lg), s = o.step(meta["t"], state, prev, det, ctrl)
+    np.testing.assert_array_equal(s[4].numpy(), g["k"])
+    np.testing.assert_allclose(lw.numpy(), g["logp_w"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(lg.numpy(), g["logp_g"], atol=1e-5, rtol=0)
+    for got, key in zip(s[:4], ("h1", "c1", "h2", "c2")):
+        np.testing.assert_allclose(got.numpy(), g[key], atol=1e-6, rtol=0)
+
+
+def test_full_size_greedy_beam_sample_subset():
+    """first 24 of the 256 full-size samples (the whole set is checked on the GPU box and at generation time)."""
+    meta, g = load_golden("g2_greedy")
+    _, gb = load_golden("g3_beam")
+    meta5, g5 = load_golden("g5_sample")
+    o, _ = _oracle(meta)
+    n = 24
+    det, ctrl = helpers.decode_inputs(meta["cfg"], meta["seed"], n=n)
+    with torch.no_grad():
+        w, gate, marg, ks, _ = o.test(det, ctrl, return_trace=True)
+        np.testing.assert_array_equal(w.numpy(), g["words"][:n])
+        np.testing.assert_array_equal(gate.numpy(), g["gates"][:n])
+        np.testing.assert_array_equal(ks.numpy(), g["slots"][:n])
+        (bw, bg), _ = o.beam_search(det, ctrl, meta["eos"], 5, 1)
+        solid = gb["agree64"][:n].astype(bool)
+        assert ((bw.numpy() == gb["words"][:n]).all(1) & (bg.numpy() == gb["gates"][:n]).all(1))[solid].all()
+        fw, fg = torch.from_numpy(g5["words"][:n].astype(np.int64)), torch.from_numpy(g5["gates"][:n].astype(np.int64))
+        _, (lw, lg) = o.sample_rl(det, ctrl, forced=(fw, fg))
+        np.testing.assert_allclose(lw.numpy(), g5["lp_w"][:n], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(lg.numpy(), g5["lp_g"][:n], atol=1e-4, rtol=0)
+    # the fixture really is diverse and well separated
+    assert len(np.unique(g["words"])) >= 200 and 0.2 <= g["gates"].mean() <= 0.8
+    assert (g["slots"][:, -1] == meta["cfg"]["L"] - 1).any()
+    assert g["margins"][:, :, 0].min() >= 2e-4 and g["margins"][:, :, 1].min() >= 2e-3
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference not mounted (GPU box)")
+def test_live_against_reference(tmp_path, monkeypatch):
+    import json
+    import subprocess
+    import sys
+    # run in a subprocess: the reference's package is also called `models`
+    code = r'''
+import sys, json, os
+sys.path.insert(0, "/root/reference"); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, numpy as np
+from vsrcap import synth
+import vsr_oracle as vo
+from models import ControllableCaptioningModel
+c = dict(V=61, B=3, R0=6, R=5, D=128, L=4, T=7, E=32, H=48, A=16)
+w = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=4)
+m = ControllableCaptioningModel(c["T"], c["V"], 2, det_feat_size=c["D"], input_encoding_size=c["E"], rnn_size=c["H"], att_size=c["A"]).eval()
+m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+det = torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=2)); ctrl = torch.from_numpy(synth.make_ctrl(c["B"], c["L"], c["R"], c["D"], seed=2))
+for aw in (True, False):
+    o = vo.Oracle(w, c["T"], 2, as_written=aw)
+    with torch.no_grad():
+        a = m.test(det, ctrl); b = o.test(det, ctrl)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+        (a, _) = m.beam_search((det, ctrl), [3, -1], 4, 2); (b, _) = o.beam_search(det, ctrl, [3, -1], 4, 2)
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+print("LIVE-OK")
+''' % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vsr-guided-cic_amd"),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    (tmp_path / "datasets" / "coco").mkdir(parents=True)
+    (tmp_path / "datasets" / "coco" / "verb_2_vob_all_refine.json").write_text("{}")
+    (tmp_path / "datasets" / "coco" / "verb_2_vob.json").write_text("{}")
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert "LIVE-OK" in r.stdout, r.stderr[-2000:]

@@ -1,0 +1,40 @@
+"""Build libvsrcap.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python vsr-guided-cic_amd/build.py [--force]
+
+The shared library lands next to the ctypes binding (vsr-guided-cic_amd/vsrcap/libvsrcap.so) so that
+it travels to the GPU box with the repo snapshot; it is git-ignored (source-only history).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "vsrcap.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "gemm_f32.h"), os.path.join(HERE, "csrc", "kernels.h"),
+        os.path.join(HERE, "csrc", "train_kernels.h"),
+        os.path.join(os.path.dirname(HERE), "include", "vsrcap.h")]
+OUT = os.path.join(HERE, "vsrcap", "libvsrcap.so")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT + ".tmp", SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.run(cmd, check=True)
+    os.replace(OUT + ".tmp", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,688 @@
+// Pointwise / reduction kernels of the decoder step (everything that is not a GEMM).
+// Reference equations: /root/reference/models/controllable_captioning.py:117-190 (step), :192-297 (step_v);
+// loops: /root/reference/models/CaptioningModel.py:38-76 (greedy, sampling), :116-294 (beam search).
+// All arithmetic is fp32 with accurate expf/tanhf/logf (no fast-math), wave64 shuffles for reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsr {
+
+constexpr int KMAX = 8;  // VSR_MAX_BEAM
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-contiguous dealing of n work items over a grid of 8*ceil(n/8) blocks: rows of one image (adjacent
+// items) land on the same XCD and share its L2.  Returns -1 for the padding blocks.
+__device__ __forceinline__ int xcd_item(int n) {
+    const int chunk = (n + 7) >> 3;
+    const int it = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    return it < n ? it : -1;
+}
+
+// ---------------------------------------------------------------------------------------------- prepare
+// pooled descriptor vbar[b] = sum_r det[b,r,:] / #(rows with non-zero sum)           (step :126-128)
+__global__ __launch_bounds__(256) void k_pool(const float* __restrict__ det, int R0, int D, float* __restrict__ vbar) {
+    __shared__ float cnt_s[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* X = det + (long long)b * R0 * D;
+    float cnt = 0.f;
+    for (int r = wave; r < R0; r += 4) {
+        float s = 0.f;
+        for (int d = lane * 4; d < D; d += 256) {
+            float4 v = *reinterpret_cast<const float4*>(X + (long long)r * D + d);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        s = wave_sum(s);
+        cnt += (s != 0.f) ? 1.f : 0.f;
+    }
+    if (lane == 0) cnt_s[wave] = cnt;
+    __syncthreads();
+    const float n = (cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]);
+    for (int d = tid; d < D; d += 256) {
+        float s = 0.f;
+        for (int r = 0; r < R0; ++r) s += X[(long long)r * D + d];
+        vbar[(long long)b * D + d] = s / n;
+    }
+}
+
+// region-row masks m[row] = (sum_d regions[row,:] != 0), one wave per row                 (step :159)
+__global__ __launch_bounds__(256) void k_rowmask(const float* __restrict__ X, long long rows, int D, float* __restrict__ mask) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+        float4 v = *reinterpret_cast<const float4*>(X + row * D + d);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) mask[row] = (s != 0.f) ? 1.f : 0.f;
+}
+
+// hoisted image part of the LSTM1 / gate pre-activations: sum the split-K slabs and fold in all biases.
+// n in [0,4H): b_ih + b_hh of lstm_cell_1;  [4H,5H): W1_is.bias + W1_hs.bias;  [5H,6H): W1_ig.bias + W1_hg.bias
+__global__ void k_vproj_finish(const float* __restrict__ slabs, int nsplit, long long stride, int B, int H,
+                               const float* b_ih, const float* b_hh, const float* b_is, const float* b_hs,
+                               const float* b_ig, const float* b_hg, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = 6 * H;
+    if (i >= (long long)B * N) return;
+    const int n = (int)(i % N);
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slabs[k * stride + i];
+    float bias;
+    if (n < 4 * H) bias = b_ih[n] + b_hh[n];
+    else if (n < 5 * H) bias = b_is[n - 4 * H] + b_hs[n - 4 * H];
+    else bias = b_ig[n - 5 * H] + b_hg[n - 5 * H];
+    out[i] = s + bias;
+}
+
+__global__ void k_slab_reduce(const float* __restrict__ slabs, int nsplit, long long stride, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slabs[k * stride + i];
+    out[i] = s;
+}
+
+__global__ void k_fill_i32(int* p, int v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_i64_to_i32(const int64_t* src, long long src_stride, int* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (int)src[(long long)i * src_stride];
+}
+__global__ void k_i32_to_i64(const int* src, int64_t* dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------- step
+// LSTM1 + sentinel gate + image part of the shift gate                                (step :151-154, :181)
+// pre: (nsplit, M, 6H) raw GEMM sums of [h2 | x | h1_old]; vproj: (B, 6H) hoisted vbar part + biases.
+__global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ vproj,
+                        int rpi, const int* __restrict__ parent, const float* __restrict__ c1_old, int M, int H,
+                        float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * H) return;
+    const int row = (int)(i / H), j = (int)(i % H);
+    const long long base = (long long)row * 6 * H + j;
+    const float* vp = vproj + (long long)(row / rpi) * 6 * H + j;
+    float q[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        q[g] = s + vp[(long long)g * H];
+    }
+    const int prow = parent ? parent[row] : row;
+    const float c_old = c1_old[(long long)prow * H + j];
+    const float c = sigmoidf_(q[1]) * c_old + sigmoidf_(q[0]) * tanhf(q[2]);
+    const float tc = tanhf(c);
+    h1n[i] = sigmoidf_(q[3]) * tc;
+    c1n[i] = c;
+    s_t[i] = sigmoidf_(q[4]) * tc;
+    gpre[i] = q[5];
+}
+
+// reduce the slabs of h1 -> [W1_hg | att_ha] and s_t -> [s_fc | att_sa]; finish the shift-gate vector
+// g_t = sigmoid(gpre + W1_hg h1_new) * tanh(c1_new)                                     (step :155, :181-182)
+__global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__ c2b, int nsplit, long long stride_a,
+                        long long stride_b, const float* __restrict__ gpre, const float* __restrict__ c1n,
+                        const float* __restrict__ b_sfc, int M, int H, int A, int D, float* __restrict__ g_t,
+                        float* __restrict__ hA, float* __restrict__ sent, float* __restrict__ sa) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = H + A + D + A;
+    if (i >= (long long)M * W) return;
+    const int row = (int)(i / W), c = (int)(i % W);
+    if (c < H + A) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += c2a[k * stride_a + (long long)row * (H + A) + c];
+        if (c < H) {
+            const long long o = (long long)row * H + c;
+            g_t[o] = sigmoidf_(gpre[o] + s) * tanhf(c1n[o]);
+        } else {
+            hA[(long long)row * A + (c - H)] = s;
+        }
+    } else {
+        const int cc = c - (H + A);
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += c2b[k * stride_b + (long long)row * (D + A) + cc];
+        if (cc < D) sent[(long long)row * D + cc] = s + b_sfc[cc];
+        else sa[(long long)row * A + (cc - D)] = s;
+    }
+}
+
+// adaptive attention over [sentinel ; regions of the current slot]                    (step :158-171, :187)
+// one 256-thread workgroup per row; regions / projections are indexed by (image, slot), never copied.
+//   z_det[r] = w_a . tanh(P[img,slot,r,:] + hA)      z_sent = w_s . tanh(sa + hA)
+//   alpha    = softmax([z_sent ; z_det]) * mask ; alpha /= sum(alpha)
+//   att      = alpha_0 * sentinel + sum_r alpha_r * regions[img,slot,r,:]
+//   zsum     = sum_r mask_r * z_det[r]   (raw logits: the "shift" logit of the gate)
+__global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, const float* __restrict__ sa,
+                                                const float* __restrict__ sent, const float* __restrict__ P,
+                                                const float* __restrict__ regions, const float* __restrict__ rmask,
+                                                const int* __restrict__ slot, int fixed_slot, int rpi, int M, int L,
+                                                int R, int A, int D, const float* __restrict__ w_a,
+                                                const float* __restrict__ w_s, float* __restrict__ att,
+                                                float* __restrict__ zsum, float* __restrict__ alpha_out) {
+    extern __shared__ float sm[];
+    float* hA_s = sm;             // A
+    float* z_s = sm + A;          // R + 1  (then alpha)
+    float* red = z_s + R + 1;     // 8
+    const int row = xcd_item(M);
+    if (row < 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = row / rpi;
+    const int k = slot ? slot[row] : fixed_slot;
+    const long long sl = (long long)img * L + k;
+    for (int a = tid; a < A; a += 256) hA_s[a] = hA[(long long)row * A + a];
+    __syncthreads();
+
+    // scores: wave w takes regions w, w+4, ...; wave 3 also takes the sentinel at the end
+    const float* Pk = P + sl * R * A;
+    for (int r = wave; r < R + 1; r += 4) {
+        const float* src = (r < R) ? Pk + (long long)r * A : sa + (long long)row * A;
+        const float* wv = (r < R) ? w_a : w_s;
+        float s = 0.f;
+        for (int a = lane * 4; a < A; a += 256) {
+            const float4 p = *reinterpret_cast<const float4*>(src + a);
+            const float4 h = *reinterpret_cast<const float4*>(hA_s + a);
+            const float4 w = *reinterpret_cast<const float4*>(wv + a);
+            s += w.x * tanhf(p.x + h.x);
+            s += w.y * tanhf(p.y + h.y);
+            s += w.z * tanhf(p.z + h.z);
+            s += w.w * tanhf(p.w + h.w);
+        }
+        s = wave_sum(s);
+        if (lane == 0) z_s[(r < R) ? r + 1 : 0] = s;
+    }
+    // sentinel row-sum for its mask
+    const float* srow = sent + (long long)row * D;
+    float ss = 0.f;
+    for (int d = tid * 4; d < D; d += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(srow + d);
+        ss += (v.x + v.y) + (v.z + v.w);
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+
+    if (wave == 0) {
+        const float m0 = (((red[0] + red[1]) + (red[2] + red[3])) != 0.f) ? 1.f : 0.f;
+        const float* mk = rmask + sl * R;
+        // R + 1 <= 64 handled by one pass per 64 entries
+        float mx = -INFINITY;
+        for (int j = lane; j < R + 1; j += 64) mx = fmaxf(mx, z_s[j]);
+        mx = wave_max(mx);
+        float se = 0.f, zs = 0.f;
+        for (int j = lane; j < R + 1; j += 64) se += expf(z_s[j] - mx);
+        se = wave_sum(se);
+        float s2 = 0.f;
+        for (int j = lane; j < R + 1; j += 64) {
+            const float m = (j == 0) ? m0 : mk[j - 1];
+            const float z = z_s[j];
+            if (j > 0) zs += m * z;
+            s2 += (expf(z - mx) / se) * m;
+        }
+        s2 = wave_sum(s2);
+        zs = wave_sum(zs);
+        for (int j = lane; j < R + 1; j += 64) {
+            const float m = (j == 0) ? m0 : mk[j - 1];
+            const float al = ((expf(z_s[j] - mx) / se) * m) / s2;
+            z_s[j] = al;
+            if (alpha_out) alpha_out[(long long)row * (R + 1) + j] = al;
+        }
+        if (lane == 0) zsum[row] = zs;
+    }
+    __syncthreads();
+
+    const float* Xk = regions + sl * R * D;
+    const float a0 = z_s[0];
+    for (int d = tid * 4; d < D; d += 1024) {
+        const float4 s = *reinterpret_cast<const float4*>(srow + d);
+        float4 acc = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
+        for (int r = 0; r < R; ++r) {
+            const float al = z_s[r + 1];
+            if (al != 0.f) {   // masked (zero) rows carry alpha == 0 exactly: skip their HBM read
+                const float4 x = *reinterpret_cast<const float4*>(Xk + (long long)r * D + d);
+                acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
+            }
+        }
+        *reinterpret_cast<float4*>(att + (long long)row * D + d) = acc;
+    }
+}
+
+// LSTM2 pointwise                                                                     (step :176-177)
+__global__ void k_lstm2(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ b_ih,
+                        const float* __restrict__ b_hh, const float* __restrict__ vproj2, int rpi,
+                        const int* __restrict__ parent, const float* __restrict__ c2_old, int M, int H,
+                        float* __restrict__ h2n, float* __restrict__ c2n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * H) return;
+    const int row = (int)(i / H), j = (int)(i % H);
+    const long long base = (long long)row * 4 * H + j;
+    float q[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        s += b_ih[g * H + j] + b_hh[g * H + j];
+        if (vproj2) s += vproj2[(long long)(row / rpi) * 4 * H + g * H + j];
+        q[g] = s;
+    }
+    const int prow = parent ? parent[row] : row;
+    const float c = sigmoidf_(q[1]) * c2_old[(long long)prow * H + j] + sigmoidf_(q[0]) * tanhf(q[2]);
+    h2n[i] = sigmoidf_(q[3]) * tanhf(c);
+    c2n[i] = c;
+}
+
+// shift-gate log-probabilities: z_g = w_g . tanh(att_ga g_t + hA); gate = log_softmax([z_g, zsum])   (:184-188)
+// verb-forced rows get [-1e3, 0] (step_v :271, :295).  one wave per row.
+__global__ __launch_bounds__(256) void k_gatelogit(const float* __restrict__ ga, int nsplit, long long stride,
+                                                   const float* __restrict__ hA, const float* __restrict__ w_g,
+                                                   const float* __restrict__ zsum, const float* __restrict__ verbs,
+                                                   const int* __restrict__ slot, int rpi, int L, int M, int A,
+                                                   float* __restrict__ lg, long long lg_stride) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int a = lane; a < A; a += 64) {
+        float g = 0.f;
+        for (int k = 0; k < nsplit; ++k) g += ga[k * stride + (long long)row * A + a];
+        s += w_g[a] * tanhf(g + hA[(long long)row * A + a]);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float a = s, b = zsum[row];
+        const float mx = fmaxf(a, b);
+        const float lse = mx + logf(expf(a - mx) + expf(b - mx));
+        float l0 = a - lse, l1 = b - lse;
+        if (verbs) {
+            const float v = verbs[(long long)(row / rpi) * L + slot[row]];
+            if (v != -1.f) { l0 = -1e3f; l1 = 0.f; }
+        }
+        lg[(long long)row * lg_stride] = l0;
+        lg[(long long)row * lg_stride + 1] = l1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- vocab rows
+struct Philox {
+    // Philox4x32-10 (Salmon et al., SC'11)
+    static __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    static __device__ __forceinline__ void gen(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) {
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+        uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+    }
+    static __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+};
+
+struct TopEntry { float v; int i; };
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+enum VocabMode { VM_TOPK = 0, VM_SAMPLE = 1, VM_FORCED = 2, VM_FULL = 3 };
+
+// Per row: logits = sum of slabs + bias; log-sum-exp; then by mode
+//   VM_TOPK   K best (log-prob, id) pairs (K = 1: greedy arg-max)          (CaptioningModel.py:47, :152)
+//   VM_SAMPLE Gumbel-max draw from Categorical(logits) + its log-prob      (:66-70)
+//   VM_FORCED log-prob of a given id (sampling replay)
+//   VM_FULL   the whole log_softmax row is written to full_out             (step :178, forward :34)
+// Verb-forced rows (step_v :268-293) emit one word with log-prob 0 and -1e6 elsewhere.
+template <int K>
+__global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits, int nsplit, long long stride,
+                                               const float* __restrict__ bias, int M, int V, int mode,
+                                               float* __restrict__ top_v, int* __restrict__ top_i,
+                                               float* __restrict__ full_out, long long full_stride,
+                                               const int* __restrict__ forced, uint64_t seed, uint32_t t,
+                                               const float* __restrict__ verbs, const int* __restrict__ slot, int rpi,
+                                               int L, int gt, const int* __restrict__ vt_ptr,
+                                               const int* __restrict__ vt_ids, int n_verbs) {
+    __shared__ float sv[256 * K];
+    __shared__ int si[256 * K];
+    __shared__ float red[8];
+    __shared__ int redi[8];
+    __shared__ int pick_s;
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = logits + (long long)row * V;
+
+    // ---- verb forcing: thread 0 resolves the forced word, everybody takes the short path
+    int verb = -1;
+    if (verbs) {
+        const float vf = verbs[(long long)(row / rpi) * L + slot[row]];
+        verb = (vf != -1.f) ? (int)vf : -1;
+    }
+    if (verb != -1) {
+        if (tid == 0) {
+            int pick = 0;
+            if (gt) pick = verb;
+            else if (verb >= 0 && verb < n_verbs && vt_ptr[verb + 1] > vt_ptr[verb]) {
+                float best = -1e6f;
+                pick = -1;
+                // the reference compares log-probs; logits differ by the row constant lse, so compare
+                // logit - lse > -1e6 <=> always true for finite logits: first strict maximum wins
+                for (int q = vt_ptr[verb]; q < vt_ptr[verb + 1]; ++q) {
+                    const int id = vt_ids[q];
+                    float x = bias[id];
+                    for (int k = 0; k < nsplit; ++k) x += src[k * stride + id];
+                    if (pick < 0 || x > best) { best = x; pick = id; }
+                }
+            }
+            pick_s = pick;
+        }
+        __syncthreads();
+        const int pick = pick_s;
+        if (mode == VM_FULL) {
+            for (int v = tid; v < V; v += 256) full_out[(long long)row * full_stride + v] = (v == pick) ? 0.f : -1e6f;
+        } else if (mode == VM_TOPK) {
+            if (tid < K) {   // the forced word first, then the lowest other ids at -1e6 (ties are arbitrary in the reference)
+                int id = (tid == 0) ? pick : ((tid - 1 < pick) ? tid - 1 : tid);
+                top_v[(long long)row * K + tid] = (tid == 0) ? 0.f : -1e6f;
+                top_i[(long long)row * K + tid] = id;
+            }
+        } else if (tid == 0) {
+            int id = (mode == VM_FORCED) ? forced[row] : pick;   // Categorical over {0, -1e6...} is a point mass
+            top_v[row] = (id == pick) ? 0.f : -1e6f;
+            top_i[row] = id;
+        }
+        return;
+    }
+
+    // ---- pass 1: max and per-thread top-K (of logits, or of Gumbel-perturbed logits when sampling)
+    float tv[K];
+    int ti[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
+    float mx = -INFINITY;
+    const int V4 = (V + 3) & ~3;
+    for (int v0 = tid * 4; v0 < V4; v0 += 1024) {
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        if (mode == VM_SAMPLE) Philox::gen(seed, (uint32_t)(v0 >> 2), (uint32_t)row, t, 0u, rnd);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = v0 + e;
+            if (v < V) {
+                float x = bias[v];
+                for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
+                mx = fmaxf(mx, x);
+                float key = x;
+                if (mode == VM_SAMPLE) key = x - logf(-logf(Philox::u01(rnd[e])));
+                if (mode == VM_TOPK || mode == VM_SAMPLE) {
+                    if (better(key, v, tv[K - 1], ti[K - 1])) {
+                        tv[K - 1] = key; ti[K - 1] = v;
+#pragma unroll
+                        for (int q = K - 1; q > 0; --q)
+                            if (better(tv[q], ti[q], tv[q - 1], ti[q - 1])) {
+                                const float fv = tv[q]; tv[q] = tv[q - 1]; tv[q - 1] = fv;
+                                const int fi = ti[q]; ti[q] = ti[q - 1]; ti[q - 1] = fi;
+                            }
+                    }
+                }
+            }
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+
+    // ---- pass 2: sum of exp
+    float se = 0.f;
+    for (int v = tid; v < V; v += 256) {
+        float x = bias[v];
+        for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
+        se += expf(x - mx);
+    }
+    se = wave_sum(se);
+    if (lane == 0) red[4 + wave] = se;
+    __syncthreads();
+    const float lse = mx + logf((red[4] + red[5]) + (red[6] + red[7]));
+
+    if (mode == VM_FULL) {
+        for (int v = tid; v < V; v += 256) {
+            float x = bias[v];
+            for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
+            full_out[(long long)row * full_stride + v] = x - lse;
+        }
+        return;
+    }
+    if (mode == VM_FORCED) {
+        if (tid == 0) {
+            const int id = forced[row];
+            float x = bias[id];
+            for (int k = 0; k < nsplit; ++k) x += src[k * stride + id];
+            top_v[row] = x - lse;
+            top_i[row] = id;
+        }
+        return;
+    }
+
+    // ---- block merge of the per-thread lists: K rounds of block arg-max
+#pragma unroll
+    for (int q = 0; q < K; ++q) { sv[tid * K + q] = tv[q]; si[tid * K + q] = ti[q]; }
+    __syncthreads();
+    int head = 0;   // my list is sorted: entries before head are already taken
+    const int nk = (mode == VM_SAMPLE) ? 1 : K;
+    for (int round = 0; round < nk; ++round) {
+        float bv = (head < K) ? sv[tid * K + head] : -INFINITY;
+        int bi = (head < K) ? si[tid * K + head] : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
+        __syncthreads();
+        float gv = red[0];
+        int gi = redi[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (better(red[w], redi[w], gv, gi)) { gv = red[w]; gi = redi[w]; }
+        if (head < K && si[tid * K + head] == gi) ++head;
+        if (tid == 0) {
+            if (mode == VM_SAMPLE) {
+                float x = bias[gi];
+                for (int k = 0; k < nsplit; ++k) x += src[k * stride + gi];
+                top_v[row] = x - lse;
+                top_i[row] = gi;
+            } else {
+                top_v[(long long)row * K + round] = gv - lse;
+                top_i[(long long)row * K + round] = gi;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- selection
+// greedy / sampling / replay: next word and gate per row, advance the slot pointer     (:47, :66-70, step :135-140)
+__global__ void k_select_simple(int mode, const float* __restrict__ top_v, const int* __restrict__ top_i,
+                                const float* __restrict__ lg, const int* __restrict__ forced_gate, uint64_t seed,
+                                uint32_t t, const int* __restrict__ slot, int L, int M, int T,
+                                int* __restrict__ word_next, int* __restrict__ gate_next, int* __restrict__ slot_next,
+                                int64_t* __restrict__ words, int64_t* __restrict__ gates, float* __restrict__ lp_w,
+                                float* __restrict__ lp_g) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= M) return;
+    const float l0 = lg[row * 2], l1 = lg[row * 2 + 1];
+    int g;
+    if (mode == VM_TOPK) g = (l1 > l0) ? 1 : 0;                       // torch.max: first maximum on ties
+    else if (mode == VM_FORCED) g = forced_gate[row];
+    else {
+        uint32_t rnd[4];
+        Philox::gen(seed, 0xFFFFFFFFu, (uint32_t)row, t, 1u, rnd);
+        g = (Philox::u01(rnd[0]) < expf(l0)) ? 0 : 1;
+    }
+    const int w = top_i[row];
+    word_next[row] = w;
+    gate_next[row] = g;
+    int k = slot[row] + g;
+    slot_next[row] = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);
+    words[(long long)row * T + t] = w;
+    gates[(long long)row * T + t] = g;
+    if (lp_w) lp_w[(long long)row * T + t] = top_v[row];
+    if (lp_g) lp_g[(long long)row * T + t] = g ? l1 : l0;
+}
+
+// joint (word x gate) beam selection, one wave per image                       (CaptioningModel.py:136-180)
+// candidates: cb beams x K best words x 2 gates; score = seq + (lw + lg) in that association.
+template <int K>
+__global__ __launch_bounds__(64) void k_select_beam(int t, int cb, int beam, int L, int64_t eos_w, int64_t eos_g,
+                                                    const float* __restrict__ top_v, const int* __restrict__ top_i,
+                                                    const float* __restrict__ lg, const int* __restrict__ slot,
+                                                    const int* __restrict__ word_prev, const int* __restrict__ gate_prev,
+                                                    const float* __restrict__ seq_in, float* __restrict__ seq_out,
+                                                    const float* __restrict__ mask_in, float* __restrict__ mask_out,
+                                                    int* __restrict__ word_next, int* __restrict__ gate_next,
+                                                    int* __restrict__ slot_next, int* __restrict__ parent_row,
+                                                    int* __restrict__ hist_parent, int* __restrict__ hist_word,
+                                                    int* __restrict__ hist_gate, float* __restrict__ hist_lpw,
+                                                    float* __restrict__ hist_lpg, int B) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ float mw_s[KMAX], mg_s[KMAX];
+    // stream masks of the CURRENT beams (updated with the outputs selected at t-1)
+    if (lane < cb) {
+        float mw = 1.f, mg = 1.f;
+        if (t > 0) {
+            mw = mask_in[(b * beam + lane) * 2] * ((word_prev[b * cb + lane] != eos_w) ? 1.f : 0.f);
+            mg = mask_in[(b * beam + lane) * 2 + 1] * ((gate_prev[b * cb + lane] != eos_g) ? 1.f : 0.f);
+        }
+        mw_s[lane] = mw;
+        mg_s[lane] = mg;
+    }
+    __syncthreads();
+    const int ncand = cb * K * 2;
+    // each lane owns up to 2 candidates (ncand <= 128)
+    float cv[2];
+    int cj[2], cw[2], cg[2];
+    long long cflat[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = lane + 64 * u;
+        cv[u] = -INFINITY; cj[u] = 0; cw[u] = 0; cg[u] = 0; cflat[u] = 0x7fffffffffffffffLL;
+        if (c < ncand) {
+            const int j = c / (2 * K), i = (c / 2) % K, g = c & 1;
+            const int row = b * cb + j;
+            const float seq = (t > 0) ? seq_in[b * beam + j] : 0.f;
+            const float alive = fminf(fmaxf(mw_s[j] + mg_s[j], 0.f), 1.f);
+            int w;
+            float val;
+            if (alive != 0.f) {
+                w = top_i[(long long)row * K + i];
+                val = seq + (top_v[(long long)row * K + i] + lg[row * 2 + g]);
+            } else {            // frozen hypothesis: word 0 keeps the old score, everything else -999
+                w = i;
+                val = (i == 0) ? seq : -999.f;
+            }
+            cv[u] = val; cj[u] = j; cw[u] = w; cg[u] = g;
+            cflat[u] = ((long long)j * 0x40000000LL + w) * 2 + g;
+        }
+    }
+    for (int q = 0; q < beam; ++q) {
+        // wave arg-max with deterministic tie-break on the flat (beam, word, gate) index
+        int u_best = 0;
+        if (cv[1] > cv[0] || (cv[1] == cv[0] && cflat[1] < cflat[0])) u_best = 1;
+        float bv = cv[u_best];
+        long long bf = cflat[u_best];
+        int bl = lane * 2 + u_best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const long long of = __shfl_xor(bf, o, 64);
+            const int ol = __shfl_xor(bl, o, 64);
+            if (ov > bv || (ov == bv && of < bf)) { bv = ov; bf = of; bl = ol; }
+        }
+        if ((bl >> 1) == lane) {
+            const int u = bl & 1;
+            const int j = cj[u], w = cw[u], g = cg[u];
+            const int orow = b * beam + q, prow = b * cb + j;
+            seq_out[orow] = bv;
+            word_next[orow] = w;
+            gate_next[orow] = g;
+            parent_row[orow] = prow;
+            int k = slot[prow] + g;
+            slot_next[orow] = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);
+            mask_out[orow * 2] = mw_s[j];
+            mask_out[orow * 2 + 1] = mg_s[j];
+            const long long hrow = (long long)t * B * beam + orow;
+            hist_parent[hrow] = j;
+            hist_word[hrow] = w;
+            hist_gate[hrow] = g;
+            // returned per-slot log-probs: log-prob of the selection, zeroed once its stream saw EOS
+            float lw = 0.f;
+            {   // find the word's log-prob among the parent's top-K list (frozen rows: not in the list -> use 0 * mask)
+                const float alive = fminf(fmaxf(mw_s[j] + mg_s[j], 0.f), 1.f);
+                if (alive != 0.f) {
+                    for (int i = 0; i < K; ++i)
+                        if (top_i[(long long)prow * K + i] == w) { lw = top_v[(long long)prow * K + i]; break; }
+                }
+            }
+            hist_lpw[hrow] = lw * mw_s[j];
+            hist_lpg[hrow] = lg[prow * 2 + g] * mg_s[j];
+            cv[u] = -INFINITY;
+            cflat[u] = 0x7fffffffffffffffLL;
+        }
+    }
+}
+
+// final ordering by sequence log-prob + back-tracking through the parent pointers      (:182-194)
+__global__ void k_backtrack(int T, int B, int beam, int out_size, const float* __restrict__ seq,
+                            const int* __restrict__ hist_parent, const int* __restrict__ hist_word,
+                            const int* __restrict__ hist_gate, const float* __restrict__ hist_lpw,
+                            const float* __restrict__ hist_lpg, int64_t* __restrict__ words, int64_t* __restrict__ gates,
+                            float* __restrict__ lp_w, float* __restrict__ lp_g, float* __restrict__ scores) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int order[KMAX];
+    for (int q = 0; q < beam; ++q) order[q] = q;
+    for (int a = 1; a < beam; ++a) {          // stable insertion sort, descending
+        const int oa = order[a];
+        const float va = seq[b * beam + oa];
+        int p = a - 1;
+        while (p >= 0 && seq[b * beam + order[p]] < va) { order[p + 1] = order[p]; --p; }
+        order[p + 1] = oa;
+    }
+    for (int o = 0; o < out_size; ++o) {
+        int q = order[o];
+        const long long dst = ((long long)b * out_size + o) * T;
+        if (scores) scores[b * out_size + o] = seq[b * beam + q];
+        for (int t = 0; t < T; ++t) {           // per-slot log-probs follow the final SLOT, not the ancestry
+            const long long hrow = (long long)t * B * beam + b * beam + order[o];
+            if (lp_w) lp_w[dst + t] = hist_lpw[hrow];
+            if (lp_g) lp_g[dst + t] = hist_lpg[hrow];
+        }
+        for (int t = T - 1; t >= 0; --t) {
+            const long long hrow = (long long)t * B * beam + b * beam + q;
+            words[dst + t] = hist_word[hrow];
+            gates[dst + t] = hist_gate[hrow];
+            q = hist_parent[hrow];
+        }
+    }
+}
+
+}  // namespace vsr

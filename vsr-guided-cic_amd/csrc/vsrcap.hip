@@ -1,0 +1,591 @@
+// libvsrcap.so - C ABI + per-timestep orchestration of the VSR captioning decoder on gfx950.
+// Entry points are declared in include/vsrcap.h; reference behaviour cited there and in kernels.h.
+//
+// One decoder timestep = 4 grouped fp32-MFMA GEMM launches + 6 small kernels, all on the caller's stream:
+//   S1  [h2 | x | h1_old] -> LSTM1 gates (4H) | sentinel gate (H) | shift-gate image part (H)      gemm
+//       k_lstm1                                                                                    pointwise
+//   S2  h1_new -> [W1_hg | att_ha] ,  s_t -> [s_fc | att_sa]                                       gemm (4 problems)
+//       k_gate2, k_attend                                                                          pointwise / HBM-bound
+//   S5  [h1_new | att | h2_old] -> LSTM2 gates (4H) ,  g_t -> att_ga                               gemm (2 problems)
+//       k_lstm2, k_gatelogit
+//   S6  h2_new -> vocabulary logits (V)                                                            gemm
+//       k_vocab (log-sum-exp + arg-max / top-k / Gumbel sample / full row), k_select_*
+// The image-constant work (pooled descriptor and its projection, att_va(regions), row masks) is hoisted
+// into vsr_prepare().  Beams never copy statics: rows index their image (row / beam) and their parent.
+#include "../../include/vsrcap.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "gemm_f32.h"
+#include "kernels.h"
+
+using namespace vsr;
+
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define LAUNCHCHK() HIPCHK(hipGetLastError())
+
+struct Ctx {
+    int B = 0, R0 = 0, L = 0, R = 0, beam = 1, Mmax = 0;
+    const float* det = nullptr;
+    const float* regions = nullptr;
+    float *vbar, *vproj, *vproj2, *P, *rmask;
+    float* st[2][4];   // h1, c1, h2, c2 double-buffered
+    int *slot[2], *word[2], *gate[2], *parent;
+    float *s_t, *gpre, *g_t, *hA, *sa, *sent, *att, *zsum, *lg, *top_v;
+    int* top_i;
+    float *seq[2], *mask[2];
+    int *hist_parent, *hist_word, *hist_gate;
+    float *hist_lpw, *hist_lpg;
+    int *cap32, *forced_w32, *forced_g32;
+    int64_t* tmp_i64;
+    float* scratch;
+    size_t scratch_floats = 0;
+};
+
+struct vsr_handle {
+    vsr_dims d;
+    vsr_weights w;
+    bool bound = false, prepared = false;
+    const int* vt_ptr = nullptr;
+    const int* vt_ids = nullptr;
+    int n_verbs = 0;
+    int gemm_tile = 64;
+    int target_units = 768;
+    Ctx c;
+};
+
+// ---------------------------------------------------------------------------------------------- workspace
+struct Bump {
+    char* base;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
+    const vsr_dims& d = h->d;
+    const size_t B = c.B, H = d.rnn_size, A = d.att_size, D = d.det_feat_size, V = d.vocab_size, T = d.seq_len;
+    const size_t M = c.Mmax, rows = B * c.L * c.R;
+    Bump b{base};
+    c.vbar = b.take<float>(B * D);
+    c.vproj = b.take<float>(B * 6 * H);
+    c.vproj2 = b.take<float>(B * 4 * H);
+    c.P = b.take<float>(rows * A);
+    c.rmask = b.take<float>(rows);
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) c.st[i][j] = b.take<float>(M * H);
+    for (int i = 0; i < 2; ++i) {
+        c.slot[i] = b.take<int>(M);
+        c.word[i] = b.take<int>(M);
+        c.gate[i] = b.take<int>(M);
+        c.seq[i] = b.take<float>(M);
+        c.mask[i] = b.take<float>(M * 2);
+    }
+    c.parent = b.take<int>(M);
+    c.s_t = b.take<float>(M * H);
+    c.gpre = b.take<float>(M * H);
+    c.g_t = b.take<float>(M * H);
+    c.hA = b.take<float>(M * A);
+    c.sa = b.take<float>(M * A);
+    c.sent = b.take<float>(M * D);
+    c.att = b.take<float>(M * D);
+    c.zsum = b.take<float>(M);
+    c.lg = b.take<float>(M * 2);
+    c.top_v = b.take<float>(M * KMAX);
+    c.top_i = b.take<int>(M * KMAX);
+    c.hist_parent = b.take<int>(T * M);
+    c.hist_word = b.take<int>(T * M);
+    c.hist_gate = b.take<int>(T * M);
+    c.hist_lpw = b.take<float>(T * M);
+    c.hist_lpg = b.take<float>(T * M);
+    c.cap32 = b.take<int>(T * M);
+    c.forced_w32 = b.take<int>(T * M);
+    c.forced_g32 = b.take<int>(T * M);
+    c.tmp_i64 = b.take<int64_t>(T * M);
+    // split-K slab scratch: the widest stage, 8 slabs
+    size_t widest = std::max({6 * H, (H + A) + (D + A), 4 * H + A, V});
+    size_t stage = std::max(M * widest, B * 6 * H);
+    c.scratch_floats = stage * 8;
+    c.scratch = b.take<float>(c.scratch_floats);
+    return (b.off + 255) & ~size_t(255);
+}
+
+// ---------------------------------------------------------------------------------------------- GEMM launch
+struct GemmBuilder {
+    GemmArgs a;
+    int tile;
+    GemmBuilder(int tile_) : tile(tile_) { memset(&a, 0, sizeof(a)); }
+    GemmProb& prob(int M, int N, float* C, int ldc) {
+        GemmProb& p = a.p[a.nprob++];
+        p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.nseg = 0;
+        return p;
+    }
+    static void seg(GemmProb& p, const float* A, int lda, const int* idx, const float* W, int ldw, int K) {
+        if (K <= 0) return;
+        GemmSeg& s = p.seg[p.nseg++];
+        s.A = A; s.lda = lda; s.a_idx = idx; s.W = W; s.ldw = ldw; s.K = K;
+    }
+    // common split count for the launch; slabs of one problem are split_stride apart
+    int finish(int target_units, size_t max_slab_floats_total) {
+        int base = 0, min_kt = 1 << 30;
+        for (int i = 0; i < a.nprob; ++i) {
+            GemmProb& p = a.p[i];
+            p.tiles_m = (p.M + tile - 1) / tile;
+            p.tiles_n = (p.N + tile - 1) / tile;
+            p.ktiles = 0;
+            for (int s = 0; s < p.nseg; ++s) p.ktiles += (p.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+            base += p.tiles_m * p.tiles_n;
+            min_kt = std::min(min_kt, p.ktiles);
+        }
+        int nsplit = (target_units + base - 1) / base;
+        nsplit = std::max(1, std::min({nsplit, 8, std::max(1, min_kt / 8)}));
+        (void)max_slab_floats_total;
+        int u = 0;
+        for (int i = 0; i < a.nprob; ++i) {
+            GemmProb& p = a.p[i];
+            p.nsplit = nsplit;
+            p.unit_begin = u;
+            u += p.tiles_m * p.tiles_n * nsplit;
+        }
+        a.total_units = u;
+        a.chunk = (u + 7) / 8;
+        return nsplit;
+    }
+    int launch(hipStream_t s) {
+        dim3 grid(a.chunk * 8), block(256);
+        if (tile == 128) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), grid, block, 0, s, a);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
+};
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------- API: lifetime
+extern "C" int vsr_abi_version(void) { return VSR_ABI_VERSION; }
+extern "C" const char* vsr_last_error(void) { return g_err; }
+
+extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
+    if (!dims || !out) return fail("vsr_create: null argument");
+    const vsr_dims& d = *dims;
+    if (d.seq_len <= 0 || d.vocab_size <= 0) return fail("vsr_create: seq_len and vocab_size must be positive");
+    if (d.det_feat_size % 4 || d.input_encoding_size % 4 || d.rnn_size % 4 || d.att_size % 4)
+        return fail("vsr_create: det_feat_size, input_encoding_size, rnn_size and att_size must be multiples of 4 "
+                    "(16-byte vector loads); got %d %d %d %d", d.det_feat_size, d.input_encoding_size, d.rnn_size, d.att_size);
+    if (d.bos_idx < 0 || d.bos_idx >= d.vocab_size) return fail("vsr_create: bos_idx out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("vsr_create: no HIP device");
+    vsr_handle* h = new vsr_handle();
+    h->d = d;
+    if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e) == 128 ? 128 : 64;
+    if (const char* e = getenv("VSR_GEMM_UNITS")) h->target_units = std::max(1, atoi(e));
+    *out = h;
+    return 0;
+}
+
+extern "C" void vsr_destroy(vsr_handle* h) { delete h; }
+
+extern "C" int vsr_bind_weights(vsr_handle* h, const vsr_weights* w) {
+    if (!h || !w) return fail("vsr_bind_weights: null argument");
+    const float* const* p = reinterpret_cast<const float* const*>(w);
+    for (size_t i = 0; i < sizeof(vsr_weights) / sizeof(float*); ++i)
+        if (!p[i]) return fail("vsr_bind_weights: weight pointer %zu is null", i);
+    h->w = *w;
+    h->bound = true;
+    return 0;
+}
+
+extern "C" int vsr_set_verb_table(vsr_handle* h, const int32_t* row_ptr, const int32_t* vocab_ids, int32_t n_verbs) {
+    if (!h) return fail("vsr_set_verb_table: null handle");
+    h->vt_ptr = row_ptr;
+    h->vt_ids = vocab_ids;
+    h->n_verbs = row_ptr ? n_verbs : 0;
+    return 0;
+}
+
+extern "C" size_t vsr_workspace_bytes(const vsr_handle* h, int32_t B, int32_t R0, int32_t L, int32_t R, int32_t beam) {
+    if (!h || B <= 0 || L <= 0 || R <= 0 || beam <= 0) return 0;
+    Ctx c;
+    c.B = B; c.R0 = R0; c.L = L; c.R = R; c.beam = beam; c.Mmax = B * beam;
+    return carve(h, c, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------- prepare
+extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R0, const float* regions, int32_t L,
+                           int32_t R, int32_t beam, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !h->bound) return fail("vsr_prepare: weights not bound");
+    if (!det || !regions || !workspace) return fail("vsr_prepare: null tensor");
+    if (B <= 0 || R0 <= 0 || L <= 0 || R <= 0) return fail("vsr_prepare: empty batch / regions");
+    if (beam < 1 || beam > VSR_MAX_BEAM) return fail("vsr_prepare: beam size %d not in [1, %d]", beam, VSR_MAX_BEAM);
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail("vsr_prepare: workspace must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const vsr_dims& d = h->d;
+    const vsr_weights& w = h->w;
+    const int H = d.rnn_size, A = d.att_size, D = d.det_feat_size, E = d.input_encoding_size;
+    Ctx& c = h->c;
+    c.B = B; c.R0 = R0; c.L = L; c.R = R; c.beam = beam; c.Mmax = B * beam;
+    c.det = det; c.regions = regions;
+    const size_t need = carve(h, c, reinterpret_cast<char*>(workspace));
+    if (need > workspace_bytes) return fail("vsr_prepare: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+    h->prepared = false;
+
+    // pooled descriptor and region-row masks
+    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, s, det, R0, D, c.vbar);
+    const long long rows = (long long)B * L * R;
+    hipLaunchKernelGGL(k_rowmask, dim3(cdiv(rows, 4)), dim3(256), 0, s, regions, rows, D, c.rmask);
+    LAUNCHCHK();
+
+    // hoisted vbar projections: columns [voff, voff + D) of the LSTM1 / gate input weights
+    const int in1 = (d.h2_first_lstm ? H : 0) + D + E;
+    const int voff = d.h2_first_lstm ? H : 0;
+    {
+        GemmBuilder g(h->gemm_tile);
+        GemmProb& p0 = g.prob(B, 4 * H, c.scratch, 6 * H);
+        GemmBuilder::seg(p0, c.vbar, D, nullptr, w.lstm1_weight_ih + voff, in1, D);
+        GemmProb& p1 = g.prob(B, H, c.scratch + 4 * H, 6 * H);
+        GemmBuilder::seg(p1, c.vbar, D, nullptr, w.W1_is_weight + voff, in1, D);
+        GemmProb& p2 = g.prob(B, H, c.scratch + 5 * H, 6 * H);
+        GemmBuilder::seg(p2, c.vbar, D, nullptr, w.W1_ig_weight + voff, in1, D);
+        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const long long stride = (long long)B * 6 * H;
+        for (int i = 0; i < 3; ++i) g.a.p[i].split_stride = stride;
+        if (g.launch(s)) return fail("vproj gemm launch failed");
+        const long long n = (long long)B * 6 * H;
+        hipLaunchKernelGGL(k_vproj_finish, dim3(cdiv(n, 256)), dim3(256), 0, s, c.scratch, ns, stride, B, H,
+                           w.lstm1_bias_ih, w.lstm1_bias_hh, w.W1_is_bias, w.W1_hs_bias, w.W1_ig_bias, w.W1_hg_bias, c.vproj);
+        LAUNCHCHK();
+    }
+    if (d.img_second_lstm) {
+        const int in2 = H + 2 * D;
+        GemmBuilder g(h->gemm_tile);
+        GemmProb& p0 = g.prob(B, 4 * H, c.scratch, 4 * H);
+        GemmBuilder::seg(p0, c.vbar, D, nullptr, w.lstm2_weight_ih + H + D, in2, D);
+        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const long long stride = (long long)B * 4 * H;
+        g.a.p[0].split_stride = stride;
+        if (g.launch(s)) return fail("vproj2 gemm launch failed");
+        hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.vproj2);
+        LAUNCHCHK();
+    }
+    // att_va over every region row of every slot: (B*L*R, D) x (A, D)^T -> P, written in place (no split)
+    {
+        GemmBuilder g(rows >= 512 ? 128 : h->gemm_tile);
+        GemmProb& p0 = g.prob((int)rows, A, c.P, A);
+        GemmBuilder::seg(p0, regions, D, nullptr, w.att_va_weight, D, D);
+        g.finish(1, 0);
+        g.a.p[0].split_stride = 0;
+        if (g.launch(s)) return fail("att_va gemm launch failed");
+        LAUNCHCHK();
+    }
+    h->prepared = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- one timestep
+struct StepIO {
+    int t, M, rpi, cur;
+    const int* parent;       // state-row gather (beam parents) or null
+    const int* word_prev;    // (M) int32
+    const int* slot;         // (M) int32 or null -> fixed_slot
+    int fixed_slot;
+    int vmode, K;
+    float* full_out; long long full_stride;
+    const int* forced;
+    uint64_t seed;
+    const float* verbs; int gt;
+    float* lg_out; long long lg_stride;
+    float* alpha_out;
+};
+
+static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
+    const vsr_dims& d = h->d;
+    const vsr_weights& w = h->w;
+    Ctx& c = h->c;
+    const int H = d.rnn_size, A = d.att_size, D = d.det_feat_size, E = d.input_encoding_size, V = d.vocab_size;
+    const int M = io.M;
+    const int in1 = (d.h2_first_lstm ? H : 0) + D + E;
+    const int xoff = (d.h2_first_lstm ? H : 0) + D;
+    const int in2 = H + D + (d.img_second_lstm ? D : 0);
+    float* const* so = c.st[io.cur];          // old state
+    float* const* sn = c.st[io.cur ^ 1];      // new state
+    float *h1o = so[0], *c1o = so[1], *h2o = so[2], *c2o = so[3];
+    float *h1n = sn[0], *c1n = sn[1], *h2n = sn[2], *c2n = sn[3];
+
+    // ---- S1
+    {
+        GemmBuilder g(h->gemm_tile);
+        const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
+        const float* Whh[3] = {w.lstm1_weight_hh, w.W1_hs_weight, nullptr};
+        const int Nn[3] = {4 * H, H, H};
+        const int off[3] = {0, 4 * H, 5 * H};
+        for (int i = 0; i < 3; ++i) {
+            GemmProb& p = g.prob(M, Nn[i], c.scratch + off[i], 6 * H);
+            if (d.h2_first_lstm && io.t > 0) GemmBuilder::seg(p, h2o, H, io.parent, Wih[i], in1, H);
+            GemmBuilder::seg(p, w.embed_weight, E, io.word_prev, Wih[i] + xoff, in1, E);
+            if (Whh[i] && io.t > 0) GemmBuilder::seg(p, h1o, H, io.parent, Whh[i], H, H);
+        }
+        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const long long stride = (long long)M * 6 * H;
+        for (int i = 0; i < 3; ++i) g.a.p[i].split_stride = stride;
+        if (g.launch(s)) return fail("S1 gemm launch failed");
+        hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj, io.rpi,
+                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre);
+    }
+    // ---- S2
+    {
+        GemmBuilder g(h->gemm_tile);
+        float* c2a = c.scratch;
+        float* c2b_base;
+        GemmProb& p0 = g.prob(M, H, c2a, H + A);
+        GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H);
+        GemmProb& p1 = g.prob(M, A, c2a + H, H + A);
+        GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H);
+        GemmProb& p2 = g.prob(M, D, nullptr, D + A);
+        GemmBuilder::seg(p2, c.s_t, H, nullptr, w.s_fc_weight, H, H);
+        GemmProb& p3 = g.prob(M, A, nullptr, D + A);
+        GemmBuilder::seg(p3, c.s_t, H, nullptr, w.att_sa_weight, H, H);
+        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const long long stride_a = (long long)M * (H + A), stride_b = (long long)M * (D + A);
+        c2b_base = c2a + stride_a * ns;
+        g.a.p[0].split_stride = g.a.p[1].split_stride = stride_a;
+        g.a.p[2].C = c2b_base; g.a.p[3].C = c2b_base + D;
+        g.a.p[2].split_stride = g.a.p[3].split_stride = stride_b;
+        if (g.launch(s)) return fail("S2 gemm launch failed");
+        const long long n = (long long)M * (H + A + D + A);
+        hipLaunchKernelGGL(k_gate2, dim3(cdiv(n, 256)), dim3(256), 0, s, c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n,
+                           w.s_fc_bias, M, H, A, D, c.g_t, c.hA, c.sent, c.sa);
+    }
+    // ---- attention
+    {
+        const size_t smem = (size_t)(A + c.R + 1 + 8) * sizeof(float);
+        hipLaunchKernelGGL(k_attend, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, io.slot,
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out);
+    }
+    // ---- S5
+    {
+        GemmBuilder g(h->gemm_tile);
+        GemmProb& p0 = g.prob(M, 4 * H, c.scratch, 4 * H);
+        GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H);
+        GemmBuilder::seg(p0, c.att, D, nullptr, w.lstm2_weight_ih + H, in2, D);
+        if (io.t > 0) GemmBuilder::seg(p0, h2o, H, io.parent, w.lstm2_weight_hh, H, H);
+        GemmProb& p1 = g.prob(M, A, nullptr, A);
+        GemmBuilder::seg(p1, c.g_t, H, nullptr, w.att_ga_weight, H, H);
+        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const long long stride = (long long)M * 4 * H, stride_g = (long long)M * A;
+        float* ga = c.scratch + stride * ns;
+        g.a.p[0].split_stride = stride;
+        g.a.p[1].C = ga; g.a.p[1].split_stride = stride_g;
+        if (g.launch(s)) return fail("S5 gemm launch failed");
+        hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
+                           w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n);
+        hipLaunchKernelGGL(k_gatelogit, dim3(cdiv(M, 4)), dim3(256), 0, s, ga, ns, stride_g, c.hA, w.att_g_weight, c.zsum,
+                           io.verbs, io.slot, io.rpi, c.L, M, A, io.lg_out, io.lg_stride);
+    }
+    // ---- S6
+    {
+        GemmBuilder g(h->gemm_tile);
+        GemmProb& p0 = g.prob(M, V, c.scratch, V);
+        GemmBuilder::seg(p0, h2n, H, nullptr, w.out_fc_weight, H, H);
+        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const long long stride = (long long)M * V;
+        g.a.p[0].split_stride = stride;
+        if (g.launch(s)) return fail("S6 gemm launch failed");
+#define VOCAB_ARGS c.scratch, ns, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
+                   io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs
+        if (io.K <= 1) hipLaunchKernelGGL((k_vocab<1>), dim3(M), dim3(256), 0, s, VOCAB_ARGS);
+        else if (io.K <= 2) hipLaunchKernelGGL((k_vocab<2>), dim3(M), dim3(256), 0, s, VOCAB_ARGS);
+        else if (io.K <= 4) hipLaunchKernelGGL((k_vocab<4>), dim3(M), dim3(256), 0, s, VOCAB_ARGS);
+        else hipLaunchKernelGGL((k_vocab<8>), dim3(M), dim3(256), 0, s, VOCAB_ARGS);
+#undef VOCAB_ARGS
+    }
+    LAUNCHCHK();
+    return 0;
+}
+
+static int check_ready(vsr_handle* h, const char* who) {
+    if (!h) return fail("%s: null handle", who);
+    if (!h->bound) return fail("%s: weights not bound", who);
+    if (!h->prepared) return fail("%s: vsr_prepare() has not been called", who);
+    return 0;
+}
+
+static int zero_state(vsr_handle* h, int M, hipStream_t s) {
+    Ctx& c = h->c;
+    const size_t n = (size_t)M * h->d.rnn_size * sizeof(float);
+    for (int j = 0; j < 4; ++j) HIPCHK(hipMemsetAsync(c.st[0][j], 0, n, s));
+    HIPCHK(hipMemsetAsync(c.slot[0], 0, (size_t)M * sizeof(int), s));
+    hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, c.word[0], h->d.bos_idx, M);
+    LAUNCHCHK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- greedy / sampling
+static int decode_simple(vsr_handle* h, int vmode, uint64_t seed, const int64_t* forced_w, const int64_t* forced_g,
+                         const float* verbs, int gt, int64_t* words, int64_t* gates, float* lp_w, float* lp_g, hipStream_t s) {
+    Ctx& c = h->c;
+    const int B = c.B, T = h->d.seq_len;
+    if (verbs && vmode != VM_TOPK) return fail("verb forcing is only defined for greedy / beam decoding");
+    if (zero_state(h, B, s)) return 1;
+    if (vmode == VM_FORCED) {
+        for (int t = 0; t < T; ++t) {
+            hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, forced_w + t, (long long)T, c.forced_w32 + (size_t)t * B, B);
+            hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, forced_g + t, (long long)T, c.forced_g32 + (size_t)t * B, B);
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        StepIO io{};
+        io.t = t; io.M = B; io.rpi = 1; io.cur = cur;
+        io.parent = nullptr; io.word_prev = c.word[cur]; io.slot = c.slot[cur]; io.fixed_slot = 0;
+        io.vmode = vmode; io.K = 1; io.full_out = nullptr; io.full_stride = 0;
+        io.forced = (vmode == VM_FORCED) ? c.forced_w32 + (size_t)t * B : nullptr;
+        io.seed = seed; io.verbs = verbs; io.gt = gt; io.lg_out = c.lg; io.lg_stride = 2; io.alpha_out = nullptr;
+        if (run_step(h, io, s)) return 1;
+        hipLaunchKernelGGL(k_select_simple, dim3(cdiv(B, 256)), dim3(256), 0, s, vmode, c.top_v, c.top_i, c.lg,
+                           (vmode == VM_FORCED) ? c.forced_g32 + (size_t)t * B : nullptr, seed, (uint32_t)t, c.slot[cur], c.L, B, T,
+                           c.word[cur ^ 1], c.gate[cur ^ 1], c.slot[cur ^ 1], words, gates, lp_w, lp_g);
+        LAUNCHCHK();
+    }
+    return 0;
+}
+
+extern "C" int vsr_greedy(vsr_handle* h, const float* verbs, int32_t gt, int64_t* words, int64_t* gates, void* stream) {
+    if (check_ready(h, "vsr_greedy")) return 1;
+    if (!words || !gates) return fail("vsr_greedy: null output");
+    return decode_simple(h, VM_TOPK, 0, nullptr, nullptr, verbs, gt, words, gates, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int vsr_sample(vsr_handle* h, uint64_t seed, const int64_t* forced_words, const int64_t* forced_gates,
+                          int64_t* words, int64_t* gates, float* lp_words, float* lp_gates, void* stream) {
+    if (check_ready(h, "vsr_sample")) return 1;
+    if (!words || !gates || !lp_words || !lp_gates) return fail("vsr_sample: null output");
+    if ((forced_words == nullptr) != (forced_gates == nullptr)) return fail("vsr_sample: forced_words and forced_gates go together");
+    return decode_simple(h, forced_words ? VM_FORCED : VM_SAMPLE, seed, forced_words, forced_gates, nullptr, 0, words, gates,
+                         lp_words, lp_gates, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- beam search
+extern "C" int vsr_beam(vsr_handle* h, int32_t beam, int32_t out_size, int64_t eos_word, int64_t eos_gate, const float* verbs,
+                        int32_t gt, int64_t* words, int64_t* gates, float* lp_words, float* lp_gates, float* scores, void* stream) {
+    if (check_ready(h, "vsr_beam")) return 1;
+    Ctx& c = h->c;
+    if (beam < 1 || beam > c.beam) return fail("vsr_beam: beam %d exceeds the prepared beam %d", beam, c.beam);
+    if (out_size < 1 || out_size > beam) return fail("vsr_beam: out_size %d not in [1, beam]", out_size);
+    if (!words || !gates) return fail("vsr_beam: null output");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = c.B, T = h->d.seq_len;
+    const int K = beam <= 1 ? 1 : beam <= 2 ? 2 : beam <= 4 ? 4 : 8;
+    if (zero_state(h, B, s)) return 1;
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        const int cb = t == 0 ? 1 : beam;
+        const int M = B * cb;
+        StepIO io{};
+        io.t = t; io.M = M; io.rpi = cb; io.cur = cur;
+        io.parent = t == 0 ? nullptr : c.parent; io.word_prev = c.word[cur]; io.slot = c.slot[cur]; io.fixed_slot = 0;
+        io.vmode = VM_TOPK; io.K = K; io.forced = nullptr; io.seed = 0; io.verbs = verbs; io.gt = gt;
+        io.lg_out = c.lg; io.lg_stride = 2; io.alpha_out = nullptr;
+        if (run_step(h, io, s)) return 1;
+#define SEL_ARGS t, cb, beam, c.L, eos_word, eos_gate, c.top_v, c.top_i, c.lg, c.slot[cur], c.word[cur], c.gate[cur], c.seq[cur], \
+                 c.seq[cur ^ 1], c.mask[cur], c.mask[cur ^ 1], c.word[cur ^ 1], c.gate[cur ^ 1], c.slot[cur ^ 1], c.parent,       \
+                 c.hist_parent, c.hist_word, c.hist_gate, c.hist_lpw, c.hist_lpg, B
+        if (K == 1) hipLaunchKernelGGL((k_select_beam<1>), dim3(B), dim3(64), 0, s, SEL_ARGS);
+        else if (K == 2) hipLaunchKernelGGL((k_select_beam<2>), dim3(B), dim3(64), 0, s, SEL_ARGS);
+        else if (K == 4) hipLaunchKernelGGL((k_select_beam<4>), dim3(B), dim3(64), 0, s, SEL_ARGS);
+        else hipLaunchKernelGGL((k_select_beam<8>), dim3(B), dim3(64), 0, s, SEL_ARGS);
+#undef SEL_ARGS
+        LAUNCHCHK();
+    }
+    hipLaunchKernelGGL(k_backtrack, dim3(cdiv(B, 64)), dim3(64), 0, s, T, B, beam, out_size, c.seq[T & 1], c.hist_parent, c.hist_word,
+                       c.hist_gate, c.hist_lpw, c.hist_lpg, words, gates, lp_words, lp_gates, scores);
+    LAUNCHCHK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- teacher forcing
+extern "C" int vsr_xe_forward(vsr_handle* h, const int64_t* captions, int32_t T, float* logp_words, float* logp_gates, void* stream) {
+    if (check_ready(h, "vsr_xe_forward")) return 1;
+    Ctx& c = h->c;
+    if (!captions || !logp_words || !logp_gates) return fail("vsr_xe_forward: null tensor");
+    if (T != c.L) return fail("vsr_xe_forward: captions have %d steps but prepare() saw %d region slots", T, c.L);
+    if (T > h->d.seq_len) return fail("vsr_xe_forward: T %d exceeds seq_len %d (workspace is sized by seq_len)", T, h->d.seq_len);
+    hipStream_t s = (hipStream_t)stream;
+    const int B = c.B, V = h->d.vocab_size;
+    if (zero_state(h, B, s)) return 1;
+    for (int t = 0; t < T; ++t)
+        hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, captions + t, (long long)T, c.cap32 + (size_t)t * B, B);
+    for (int t = 0; t < T; ++t) {
+        StepIO io{};
+        io.t = t; io.M = B; io.rpi = 1; io.cur = t & 1;
+        io.parent = nullptr; io.word_prev = c.cap32 + (size_t)t * B; io.slot = nullptr; io.fixed_slot = t;
+        io.vmode = VM_FULL; io.K = 1; io.full_out = logp_words + (size_t)t * V; io.full_stride = (long long)T * V;
+        io.forced = nullptr; io.seed = 0; io.verbs = nullptr; io.gt = 0;
+        io.lg_out = logp_gates + (size_t)t * 2; io.lg_stride = (long long)T * 2; io.alpha_out = nullptr;
+        if (run_step(h, io, s)) return 1;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- single step
+__global__ void k_step_slots(int t, const int64_t* slot_in, const int64_t* prev_gate, int L, int M, int* slot32, int64_t* slot_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    long long k = slot_in[i];
+    if (t > 0) {
+        k += prev_gate[i];
+        k = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);
+    }
+    slot32[i] = (int)k;
+    slot_out[i] = k;
+}
+
+extern "C" int vsr_step(vsr_handle* h, int32_t t, int32_t rows_per_image, const int64_t* prev_words, const int64_t* prev_gates,
+                        const float* h1, const float* c1, const float* h2, const float* c2, const int64_t* slot,
+                        float* h1_out, float* c1_out, float* h2_out, float* c2_out, int64_t* slot_out,
+                        const float* verbs, int32_t gt, float* logp_words, float* logp_gates, void* stream) {
+    if (check_ready(h, "vsr_step")) return 1;
+    Ctx& c = h->c;
+    if (rows_per_image < 1 || rows_per_image > c.beam) return fail("vsr_step: rows_per_image %d exceeds the prepared beam %d", rows_per_image, c.beam);
+    if (t > 0 && (!prev_words || !prev_gates)) return fail("vsr_step: previous outputs required for t > 0");
+    hipStream_t s = (hipStream_t)stream;
+    const int M = c.B * rows_per_image, H = h->d.rnn_size, V = h->d.vocab_size;
+    const size_t n = (size_t)M * H * sizeof(float);
+    const float* in[4] = {h1, c1, h2, c2};
+    float* out[4] = {h1_out, c1_out, h2_out, c2_out};
+    for (int j = 0; j < 4; ++j) HIPCHK(hipMemcpyAsync(c.st[0][j], in[j], n, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_step_slots, dim3(cdiv(M, 256)), dim3(256), 0, s, t, slot, prev_gates, c.L, M, c.slot[0], slot_out);
+    if (t == 0) hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, c.word[0], h->d.bos_idx, M);
+    else hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, prev_words, 1LL, c.word[0], M);
+    StepIO io{};
+    io.t = 1;  // state segments are always live here (the caller may pass a non-zero state at t == 0)
+    io.M = M; io.rpi = rows_per_image; io.cur = 0;
+    io.parent = nullptr; io.word_prev = c.word[0]; io.slot = c.slot[0]; io.fixed_slot = 0;
+    io.vmode = VM_FULL; io.K = 1; io.full_out = logp_words; io.full_stride = V; io.forced = nullptr; io.seed = 0;
+    io.verbs = verbs; io.gt = gt; io.lg_out = logp_gates; io.lg_stride = 2; io.alpha_out = nullptr;
+    if (run_step(h, io, s)) return 1;
+    for (int j = 0; j < 4; ++j) HIPCHK(hipMemcpyAsync(out[j], c.st[1][j], n, hipMemcpyDeviceToDevice, s));
+    return 0;
+}

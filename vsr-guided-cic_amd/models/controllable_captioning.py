@@ -1,0 +1,177 @@
+"""ControllableCaptioningModel on MI355X: the reference's class surface over libvsrcap.so.
+
+Mirrors /root/reference/models/controllable_captioning.py:
+  ctor signature and the 28 state_dict keys / shapes        :11-70
+  init_weights distributions (xavier-normal, orthogonal W_hh, zero biases)   :72-107
+  init_state / step / step_v / test / sample_rl signatures   :109-303
+Parameters are ordinary torch Parameters (so .to(), .parameters(), state_dict(), optimizers work); the
+library BORROWS their storage, nothing is copied.  All compute is in the HIP library: there is no
+PyTorch/CPU fallback, and calling a compute method with CPU tensors raises.
+"""
+import json
+import os
+
+import torch
+from torch import nn
+
+from .CaptioningModel import CaptioningModel
+from vsrcap.engine import Engine
+
+
+class ControllableCaptioningModel(CaptioningModel):
+    def __init__(self, seq_len, vocab_size, bos_idx, det_feat_size=2048, input_encoding_size=1000, rnn_size=1000,
+                 att_size=512, h2_first_lstm=True, img_second_lstm=False, dataset='coco', *, verb_2_vob_all=None):
+        super().__init__(seq_len)
+        self.vocab_size = vocab_size
+        self.bos_idx = bos_idx
+        self.det_feat_size = det_feat_size
+        self.input_encoding_size = input_encoding_size
+        self.rnn_size = rnn_size
+        self.att_size = att_size
+        self.h2_first_lstm = h2_first_lstm
+        self.img_second_lstm = img_second_lstm
+
+        # verb id -> admissible vocabulary ids, used by step_v (:25-34).  The reference opens the JSON
+        # tables relative to the CWD; verb_2_vob_all=... (keyword-only extension) supplies the table directly.
+        if verb_2_vob_all is not None:
+            self.verb_2_vob_all, self.verb_2_vob = dict(verb_2_vob_all), {}
+        else:
+            folder, names = (('datasets/coco', ('verb_2_vob_all_refine.json', 'verb_2_vob.json')) if dataset == 'coco'
+                             else ('datasets/flickr', ('verb_2_vob_all_refine_flickr.json', 'verb_2_vob_flickr.json')))
+            with open(os.path.join(folder, names[0])) as f:
+                self.verb_2_vob_all = json.load(f)
+            with open(os.path.join(folder, names[1])) as f:
+                self.verb_2_vob = json.load(f)
+
+        H, D, E, A = rnn_size, det_feat_size, input_encoding_size, att_size
+        in1 = D + E + (H if h2_first_lstm else 0)
+        in2 = H + D + (D if img_second_lstm else 0)
+        self.embed = nn.Embedding(vocab_size, E)
+        self.W1_is = nn.Linear(in1, H)
+        self.W1_hs = nn.Linear(H, H)
+        self.att_va = nn.Linear(D, A, bias=False)
+        self.att_ha = nn.Linear(H, A, bias=False)
+        self.att_a = nn.Linear(A, 1, bias=False)
+        self.att_sa = nn.Linear(H, A, bias=False)
+        self.att_s = nn.Linear(A, 1, bias=False)
+        self.lstm_cell_1 = nn.LSTMCell(in1, H)
+        self.lstm_cell_2 = nn.LSTMCell(in2, H)
+        self.out_fc = nn.Linear(H, vocab_size)
+        self.s_fc = nn.Linear(H, D)
+        self.W1_ig = nn.Linear(in1, H)
+        self.W1_hg = nn.Linear(H, H)
+        self.att_ga = nn.Linear(H, A, bias=False)
+        self.att_g = nn.Linear(A, 1, bias=False)
+        self.init_weights()
+        self._eng = None
+        self._verb_dev = None
+
+    def init_weights(self):
+        for name, p in self.named_parameters():
+            if name.endswith('weight_hh'):
+                nn.init.orthogonal_(p)
+            elif p.dim() == 2:
+                nn.init.xavier_normal_(p)
+            else:
+                nn.init.constant_(p, 0)
+
+    def init_state(self, b_s, device):
+        z = lambda: torch.zeros((b_s, self.rnn_size), dtype=torch.float32, device=device)
+        return (z(), z()), (z(), z()), torch.zeros((b_s,), dtype=torch.long, device=device)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _engine(self, device):
+        if device.type != 'cuda':
+            raise RuntimeError("ControllableCaptioningModel (MI355X build) computes only on the GPU: move the model and "
+                               "its inputs to 'cuda'. There is no CPU fallback.")
+        if self._eng is None:
+            self._eng = Engine(dict(seq_len=self.seq_len, vocab_size=self.vocab_size, bos_idx=self.bos_idx,
+                                    det_feat_size=self.det_feat_size, input_encoding_size=self.input_encoding_size,
+                                    rnn_size=self.rnn_size, att_size=self.att_size,
+                                    h2_first_lstm=int(self.h2_first_lstm), img_second_lstm=int(self.img_second_lstm)))
+            self._verb_dev = None
+        params = {k: v.data for k, v in self.named_parameters()}
+        if next(iter(params.values())).device != device:
+            raise RuntimeError("model parameters are on %s but the inputs are on %s" % (next(iter(params.values())).device, device))
+        self._eng.bind(params)
+        return self._eng
+
+    def _weights_version(self):
+        return sum(p._version for p in self.parameters())
+
+    def _verbs(self, eng, verbs, device):
+        if self._verb_dev != device:
+            eng.set_verb_table(self.verb_2_vob_all, device)
+            self._verb_dev = device
+        return verbs.to(device=device, dtype=torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ loops (CaptioningModel hooks)
+    def _run_forward(self, statics, seqs):
+        det, (captions, ctrl_seq) = statics[0], seqs
+        eng = self._engine(det.device)
+        if captions.size(1) > self.seq_len:
+            raise RuntimeError("captions longer than seq_len")
+        B = eng.prepare(det, ctrl_seq, 1, self._weights_version())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from vsrcap.train import xe_forward_with_grad
+            return xe_forward_with_grad(self, eng, det, captions, ctrl_seq)
+        return eng.xe_forward(B, det.device, captions)
+
+    def _run_greedy(self, statics, verbs=None, gt=False):
+        det, ctrl = statics[0], statics[1]
+        eng = self._engine(det.device)
+        B = eng.prepare(det, ctrl, 1, self._weights_version())
+        v = self._verbs(eng, statics[2], det.device) if len(statics) > 2 and statics[2] is not None else None
+        return eng.greedy(B, det.device, v, gt)
+
+    def _run_sample(self, statics, seed=None, forced=None):
+        det, ctrl = statics[0], statics[1]
+        eng = self._engine(det.device)
+        B = eng.prepare(det, ctrl, 1, self._weights_version())
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        outs, lps = eng.sample(B, det.device, seed, forced)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from vsrcap.train import sample_logprobs_with_grad
+            lps = sample_logprobs_with_grad(self, eng, det, ctrl, outs, lps)
+        return outs, lps
+
+    def _run_beam(self, statics, eos_idxs, beam_size, out_size, with_verbs, gt):
+        det, ctrl = statics[0], statics[1]
+        eng = self._engine(det.device)
+        B = eng.prepare(det, ctrl, beam_size, self._weights_version())
+        v = self._verbs(eng, statics[2], det.device) if with_verbs else None
+        (w, g), (lw, lg), _ = eng.beam(B, det.device, beam_size, out_size, eos_idxs[0], eos_idxs[1], v, gt)
+        if out_size == 1:
+            return [w[:, 0], g[:, 0]], [lw[:, 0], lg[:, 0]]
+        return [w, g], [lw, lg]
+
+    # ------------------------------------------------------------------ single timestep (feedback mode)
+    def step(self, t, state, prev_outputs, statics, seqs, *args, mode='teacher_forcing'):
+        return self._step(t, state, prev_outputs, statics, seqs, mode, False, False)
+
+    def step_v(self, t, state, prev_outputs, statics, seqs, *args, mode='teacher_forcing', gt=False):
+        return self._step(t, state, prev_outputs, statics, seqs, mode, True, gt)
+
+    def _step(self, t, state, prev_outputs, statics, seqs, mode, with_verbs, gt):
+        assert (mode in ['teacher_forcing', 'feedback'])
+        det = statics[0]
+        eng = self._engine(det.device)
+        if mode == 'teacher_forcing':
+            # one slot per row: regions of step t, word of step t (controllable_captioning.py:131-133)
+            regions = seqs[1][:, t:t + 1].contiguous()
+            eng.prepare(det, regions, 1, self._weights_version())
+            (h1, c1), (h2, c2), slot = state
+            prev = (seqs[0][:, t], torch.zeros_like(slot))
+            outs, (s1, s2, _) = eng.step(1, 1, prev, ((h1, c1), (h2, c2), torch.zeros_like(slot)))
+            # feeding the ground-truth word as "previous output" with gate 0 on a single slot IS teacher forcing
+            return outs, (s1, s2, slot)
+        eng.prepare(det, statics[1], 1, self._weights_version())
+        v = self._verbs(eng, statics[2], det.device) if with_verbs else None
+        return eng.step(t, 1, prev_outputs, state, v, gt)
+
+    def test(self, detections, ctrl_det_seqs_test):
+        return super().test((detections, ctrl_det_seqs_test))
+
+    def sample_rl(self, detections, ctrl_det_seqs_test, **kw):
+        return super().sample_rl((detections, ctrl_det_seqs_test), **kw)

@@ -1,0 +1,86 @@
+"""ctypes binding of libvsrcap.so (the C ABI declared in include/vsrcap.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol is absent this module raises,
+and every caller above it fails loudly (no eager-PyTorch or CPU substitute exists in this package).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvsrcap.so")
+
+WEIGHT_FIELDS = [
+    # (C field, state_dict key) in the order of struct vsr_weights
+    ("embed_weight", "embed.weight"),
+    ("W1_is_weight", "W1_is.weight"), ("W1_is_bias", "W1_is.bias"),
+    ("W1_hs_weight", "W1_hs.weight"), ("W1_hs_bias", "W1_hs.bias"),
+    ("att_va_weight", "att_va.weight"), ("att_ha_weight", "att_ha.weight"), ("att_a_weight", "att_a.weight"),
+    ("att_sa_weight", "att_sa.weight"), ("att_s_weight", "att_s.weight"),
+    ("lstm1_weight_ih", "lstm_cell_1.weight_ih"), ("lstm1_weight_hh", "lstm_cell_1.weight_hh"),
+    ("lstm1_bias_ih", "lstm_cell_1.bias_ih"), ("lstm1_bias_hh", "lstm_cell_1.bias_hh"),
+    ("lstm2_weight_ih", "lstm_cell_2.weight_ih"), ("lstm2_weight_hh", "lstm_cell_2.weight_hh"),
+    ("lstm2_bias_ih", "lstm_cell_2.bias_ih"), ("lstm2_bias_hh", "lstm_cell_2.bias_hh"),
+    ("out_fc_weight", "out_fc.weight"), ("out_fc_bias", "out_fc.bias"),
+    ("s_fc_weight", "s_fc.weight"), ("s_fc_bias", "s_fc.bias"),
+    ("W1_ig_weight", "W1_ig.weight"), ("W1_ig_bias", "W1_ig.bias"),
+    ("W1_hg_weight", "W1_hg.weight"), ("W1_hg_bias", "W1_hg.bias"),
+    ("att_ga_weight", "att_ga.weight"), ("att_g_weight", "att_g.weight"),
+]
+
+
+class VsrDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "seq_len", "vocab_size", "bos_idx", "det_feat_size", "input_encoding_size", "rnn_size", "att_size",
+        "h2_first_lstm", "img_second_lstm")]
+
+
+class VsrWeights(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f, _ in WEIGHT_FIELDS]
+
+
+P = C.c_void_p
+I32, I64, U64, SZ = C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/vsrcap.h declares
+SIGNATURES = {
+    "vsr_abi_version": (I32, []),
+    "vsr_last_error": (C.c_char_p, []),
+    "vsr_create": (I32, [C.POINTER(VsrDims), C.POINTER(P)]),
+    "vsr_destroy": (None, [P]),
+    "vsr_bind_weights": (I32, [P, C.POINTER(VsrWeights)]),
+    "vsr_set_verb_table": (I32, [P, P, P, I32]),
+    "vsr_workspace_bytes": (SZ, [P, I32, I32, I32, I32, I32]),
+    "vsr_prepare": (I32, [P, P, I32, I32, P, I32, I32, I32, P, SZ, P]),
+    "vsr_greedy": (I32, [P, P, I32, P, P, P]),
+    "vsr_sample": (I32, [P, U64, P, P, P, P, P, P, P]),
+    "vsr_beam": (I32, [P, I32, I32, I64, I64, P, I32, P, P, P, P, P, P]),
+    "vsr_xe_forward": (I32, [P, P, I32, P, P, P]),
+    "vsr_step": (I32, [P, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvsrcap.so once; raise if it (or any declared symbol) is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libvsrcap.so not found at %s: build it with `python vsr-guided-cic_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback for this path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is absent
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vsr_abi_version() != 1:
+        raise RuntimeError("libvsrcap.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libvsrcap: " + load().vsr_last_error().decode())

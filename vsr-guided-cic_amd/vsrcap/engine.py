@@ -1,0 +1,166 @@
+"""Thin host-side driver of the C ABI: owns one vsr_handle, borrows torch storage for weights / tensors /
+workspace and enqueues everything on torch's current HIP stream.  PyTorch is plumbing here (device memory,
+streams); all arithmetic happens in libvsrcap.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        t = t.float()
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (got %s); this path has no CPU implementation" % (name, t.device))
+    return t.contiguous()
+
+
+class Engine:
+    def __init__(self, dims):
+        """dims: dict with the vsr_dims fields."""
+        self.lib = _lib.load()
+        self.dims = _lib.VsrDims(**dims)
+        self.h = C.c_void_p()
+        _lib.check(self.lib.vsr_create(C.byref(self.dims), C.byref(self.h)))
+        self._bound_ptrs = None
+        self._ws = None
+        self._prep_key = None
+        self._keep = None
+        self._verb_dev = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.vsr_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights / tables
+    def bind(self, params):
+        """params: dict state_dict key -> fp32 CUDA tensor (borrowed, not copied)."""
+        ptrs = []
+        for _, key in _lib.WEIGHT_FIELDS:
+            t = params[key]
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("weight %s must be a contiguous fp32 GPU tensor (got %s %s)" % (key, t.dtype, t.device))
+            ptrs.append(t.data_ptr())
+        ptrs = tuple(ptrs)
+        if ptrs != self._bound_ptrs:
+            w = _lib.VsrWeights(*ptrs)
+            _lib.check(self.lib.vsr_bind_weights(self.h, C.byref(w)))
+            self._bound_ptrs = ptrs
+            self._prep_key = None
+        return ptrs
+
+    def set_verb_table(self, table, device):
+        """table: dict str(verb id) -> list of vocab ids (verb_2_vob_all of the reference)."""
+        ids = [int(k) for k in table.keys()]
+        n = (max(ids) + 1) if ids else 0
+        row_ptr = np.zeros(n + 1, dtype=np.int32)
+        flat = []
+        for v in range(n):
+            lst = table.get(str(v), [])
+            flat.extend(int(x) for x in lst)
+            row_ptr[v + 1] = len(flat)
+        rp = torch.from_numpy(row_ptr).to(device)
+        fl = torch.tensor(flat if flat else [0], dtype=torch.int32, device=device)
+        self._verb_dev = (rp, fl)
+        _lib.check(self.lib.vsr_set_verb_table(self.h, _ptr(rp), _ptr(fl), n))
+
+    # ------------------------------------------------------------------ hoisted statics
+    def prepare(self, det, regions, beam, weights_version=None):
+        det = _f32(det, "detections")
+        regions = _f32(regions, "region sequences")
+        if det.dim() != 3 or regions.dim() != 4 or det.size(0) != regions.size(0) or det.size(2) != regions.size(3):
+            raise RuntimeError("expected detections (B,R0,D) and regions (B,L,R,D); got %s and %s" % (tuple(det.shape), tuple(regions.shape)))
+        if det.size(2) != self.dims.det_feat_size:
+            raise RuntimeError("feature size %d != det_feat_size %d" % (det.size(2), self.dims.det_feat_size))
+        B, R0, _ = det.shape
+        _, L, R, _ = regions.shape
+        key = (det.data_ptr(), det._version, regions.data_ptr(), regions._version, B, R0, L, R, beam,
+               self._bound_ptrs, weights_version)
+        if key == self._prep_key:
+            return B
+        need = self.lib.vsr_workspace_bytes(self.h, B, R0, L, R, beam)
+        if need == 0:
+            raise RuntimeError("vsr_workspace_bytes rejected the shapes")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != det.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=det.device)
+        stream = torch.cuda.current_stream(det.device).cuda_stream
+        _lib.check(self.lib.vsr_prepare(self.h, _ptr(det), B, R0, _ptr(regions), L, R, beam, _ptr(self._ws),
+                                        self._ws.numel(), C.c_void_p(stream)))
+        self._keep = (det, regions)          # borrowed by the library until the next prepare
+        self._prep_key = key
+        return B
+
+    def _stream(self, dev):
+        return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    # ------------------------------------------------------------------ loops
+    def greedy(self, B, device, verbs=None, gt=False):
+        T = self.dims.seq_len
+        words = torch.empty(B, T, dtype=torch.int64, device=device)
+        gates = torch.empty(B, T, dtype=torch.int64, device=device)
+        _lib.check(self.lib.vsr_greedy(self.h, _ptr(verbs), int(gt), _ptr(words), _ptr(gates), self._stream(device)))
+        return words, gates
+
+    def sample(self, B, device, seed, forced=None):
+        T = self.dims.seq_len
+        words = torch.empty(B, T, dtype=torch.int64, device=device)
+        gates = torch.empty(B, T, dtype=torch.int64, device=device)
+        lpw = torch.empty(B, T, dtype=torch.float32, device=device)
+        lpg = torch.empty(B, T, dtype=torch.float32, device=device)
+        fw = fg = None
+        if forced is not None:
+            fw = forced[0].to(device=device, dtype=torch.int64).contiguous()
+            fg = forced[1].to(device=device, dtype=torch.int64).contiguous()
+        _lib.check(self.lib.vsr_sample(self.h, C.c_uint64(seed), _ptr(fw), _ptr(fg), _ptr(words), _ptr(gates), _ptr(lpw),
+                                       _ptr(lpg), self._stream(device)))
+        return (words, gates), (lpw, lpg)
+
+    def beam(self, B, device, beam, out_size, eos_word, eos_gate, verbs=None, gt=False):
+        T = self.dims.seq_len
+        words = torch.empty(B, out_size, T, dtype=torch.int64, device=device)
+        gates = torch.empty(B, out_size, T, dtype=torch.int64, device=device)
+        lpw = torch.empty(B, out_size, T, dtype=torch.float32, device=device)
+        lpg = torch.empty(B, out_size, T, dtype=torch.float32, device=device)
+        scores = torch.empty(B, out_size, dtype=torch.float32, device=device)
+        _lib.check(self.lib.vsr_beam(self.h, beam, out_size, int(eos_word), int(eos_gate), _ptr(verbs), int(gt), _ptr(words),
+                                     _ptr(gates), _ptr(lpw), _ptr(lpg), _ptr(scores), self._stream(device)))
+        return (words, gates), (lpw, lpg), scores
+
+    def xe_forward(self, B, device, captions):
+        T = captions.size(1)
+        V = self.dims.vocab_size
+        captions = captions.to(device=device, dtype=torch.int64).contiguous()
+        out = torch.empty(B, T, V, dtype=torch.float32, device=device)
+        gate = torch.empty(B, T, 2, dtype=torch.float32, device=device)
+        _lib.check(self.lib.vsr_xe_forward(self.h, _ptr(captions), T, _ptr(out), _ptr(gate), self._stream(device)))
+        return out, gate
+
+    def step(self, t, rows_per_image, prev, state, verbs=None, gt=False):
+        (h1, c1), (h2, c2), slot = state
+        dev = h1.device
+        M, V = h1.size(0), self.dims.vocab_size
+        h1, c1, h2, c2 = (_f32(x, "state") for x in (h1, c1, h2, c2))
+        slot = slot.to(torch.int64).contiguous()
+        pw = pg = None
+        if t > 0:
+            pw = prev[0].to(torch.int64).contiguous()
+            pg = prev[1].to(torch.int64).contiguous()
+        outs = [torch.empty_like(h1) for _ in range(4)]
+        slot_out = torch.empty_like(slot)
+        lw = torch.empty(M, V, dtype=torch.float32, device=dev)
+        lg = torch.empty(M, 2, dtype=torch.float32, device=dev)
+        _lib.check(self.lib.vsr_step(self.h, t, rows_per_image, _ptr(pw), _ptr(pg), _ptr(h1), _ptr(c1), _ptr(h2), _ptr(c2),
+                                     _ptr(slot), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(slot_out),
+                                     _ptr(verbs), int(gt), _ptr(lw), _ptr(lg), self._stream(dev)))
+        return (lw, lg), ((outs[0], outs[1]), (outs[2], outs[3]), slot_out)

@@ -1,0 +1,180 @@
+"""Closed-form synthetic weights and inputs for the VSR captioning decoder.
+
+Everything here is a pure function of (shape, stream id, seed) evaluated with a
+splitmix64 integer mixer in numpy uint64, so the golden-vector generator (which
+runs the reference in the build container), the CPU oracle, the GPU parity
+tests and bench.py all regenerate bit-identical fp32 tensors without any
+committed weight file and without depending on torch's RNG.
+
+Shapes follow the reference:
+  parameters  /root/reference/models/controllable_captioning.py:23-68
+  detections  (B, R0, D)        data/field.py:114-150  (zero rows = padding)
+  ctrl slots  (B, L, R, D)      data/field.py:15-112   (zero rows = padding)
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _mix(x):
+    x = x.astype(np.uint64, copy=True)
+    x ^= x >> np.uint64(30)
+    x *= _M1
+    x ^= x >> np.uint64(27)
+    x *= _M2
+    x ^= x >> np.uint64(31)
+    return x
+
+
+def hash_u01(n, stream, seed=0, offset=0):
+    """n uniform float64 numbers in [0,1): splitmix64 of (offset+i), keyed by (stream, seed)."""
+    with np.errstate(over="ignore"):
+        key = _mix(np.array([np.uint64(stream) * _GOLD + np.uint64(seed) * _M1 + np.uint64(0x1234567)], dtype=np.uint64))[0]
+        idx = np.arange(offset, offset + n, dtype=np.uint64)
+        x = _mix(idx * _GOLD + key)
+    return (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def hash_int(n, lo, hi, stream, seed=0):
+    """n integers in [lo, hi)."""
+    u = hash_u01(n, stream, seed)
+    return (lo + np.floor(u * (hi - lo))).astype(np.int64)
+
+
+def param_shapes(vocab_size, det_feat_size=2048, input_encoding_size=1000, rnn_size=1000, att_size=512,
+                 h2_first_lstm=True, img_second_lstm=False):
+    """state_dict key -> shape, in the reference's registration order
+    (controllable_captioning.py:23-68)."""
+    V, D, E, H, A = vocab_size, det_feat_size, input_encoding_size, rnn_size, att_size
+    in1 = D + E + (H if h2_first_lstm else 0)
+    in2 = H + D + (D if img_second_lstm else 0)
+    s = OrderedDict()
+    s["embed.weight"] = (V, E)
+    s["W1_is.weight"] = (H, in1); s["W1_is.bias"] = (H,)
+    s["W1_hs.weight"] = (H, H); s["W1_hs.bias"] = (H,)
+    s["att_va.weight"] = (A, D)
+    s["att_ha.weight"] = (A, H)
+    s["att_a.weight"] = (1, A)
+    s["att_sa.weight"] = (A, H)
+    s["att_s.weight"] = (1, A)
+    s["lstm_cell_1.weight_ih"] = (4 * H, in1); s["lstm_cell_1.weight_hh"] = (4 * H, H)
+    s["lstm_cell_1.bias_ih"] = (4 * H,); s["lstm_cell_1.bias_hh"] = (4 * H,)
+    s["lstm_cell_2.weight_ih"] = (4 * H, in2); s["lstm_cell_2.weight_hh"] = (4 * H, H)
+    s["lstm_cell_2.bias_ih"] = (4 * H,); s["lstm_cell_2.bias_hh"] = (4 * H,)
+    s["out_fc.weight"] = (V, H); s["out_fc.bias"] = (V,)
+    s["s_fc.weight"] = (D, H); s["s_fc.bias"] = (D,)
+    s["W1_ig.weight"] = (H, in1); s["W1_ig.bias"] = (H,)
+    s["W1_hg.weight"] = (H, H); s["W1_hg.bias"] = (H,)
+    s["att_ga.weight"] = (A, H)
+    s["att_g.weight"] = (1, A)
+    return s
+
+
+# Per-tensor gain over the xavier-uniform bound.  With gain 1 everywhere the reference emits <= 13
+# distinct tokens and almost never shifts the slot pointer.  These gains put the
+# decoder in a token-driven regime: a large embedding and input-to-hidden weights (pre-activations
+# of O(1)), weak hidden-to-hidden recurrence (so fp32 rounding differences do NOT grow from step to
+# step: measured max |logp_fp32 - logp_fp64| stays ~6e-6 over 20 steps, while hh gains >= 8 made it
+# grow 1.5x per step), peaky attention and a shift gate that fires ~30 % of the time.
+DEFAULT_GAINS = {
+    "embed.weight": 40.0,
+    "out_fc.weight": 10.0, "out_fc.bias": 1.0,
+    "att_a.weight": 3.0, "att_s.weight": 3.0, "att_g.weight": 12.0,
+    "att_va.weight": 2.0, "att_ha.weight": 2.0, "att_sa.weight": 2.0, "att_ga.weight": 2.0,
+    "lstm_cell_1.weight_ih": 4.0, "lstm_cell_1.weight_hh": 1.0,
+    "lstm_cell_2.weight_ih": 4.0, "lstm_cell_2.weight_hh": 1.0,
+    "W1_is.weight": 3.0, "W1_hs.weight": 1.0, "W1_ig.weight": 3.0, "W1_hg.weight": 1.0,
+    "s_fc.weight": 1.0,
+}
+BIAS_BOUND = 0.1
+
+
+def make_weights(vocab_size, det_feat_size=2048, input_encoding_size=1000, rnn_size=1000, att_size=512,
+                 h2_first_lstm=True, img_second_lstm=False, seed=0, gains=None):
+    """OrderedDict name -> float32 ndarray (reference layout, row-major [out, in])."""
+    g = dict(DEFAULT_GAINS)
+    if gains:
+        g.update(gains)
+    shapes = param_shapes(vocab_size, det_feat_size, input_encoding_size, rnn_size, att_size,
+                          h2_first_lstm, img_second_lstm)
+    out = OrderedDict()
+    for tid, (name, shp) in enumerate(shapes.items()):
+        n = int(np.prod(shp))
+        u = hash_u01(n, 100 + tid, seed)
+        if len(shp) == 2:
+            bound = np.sqrt(6.0 / (shp[0] + shp[1])) * g.get(name, 1.0)
+        else:
+            bound = BIAS_BOUND * g.get(name, 1.0)
+        out[name] = ((2.0 * u - 1.0) * bound).astype(np.float32).reshape(shp)
+    return out
+
+
+FEATURE_DENSITY = 0.15
+FEATURE_SCALE = 2.0
+
+
+def _sparse_relu(u):
+    """Sparse non-negative 'post-ReLU' features: ~15 % of the entries are non-zero, U(0, FEATURE_SCALE).
+    Sparse features keep the common-mode part of W.x small against its variation, which the decoder
+    needs to produce diverse tokens / slot shifts with random weights."""
+    t = 1.0 - FEATURE_DENSITY
+    return (np.maximum(0.0, u - t) * (FEATURE_SCALE / FEATURE_DENSITY)).astype(np.float32)
+
+
+def make_detections(B, R0, D, seed=0, min_valid=None):
+    """(B, R0, D) fp32 >= 0 'post-ReLU' features; rows >= n0[b] are exactly zero, n0 in [min_valid, R0]."""
+    if min_valid is None:
+        min_valid = max(1, (R0 * 10) // 36)
+    u = hash_u01(B * R0 * D, 1, seed).reshape(B, R0, D)
+    x = _sparse_relu(u)
+    n0 = hash_int(B, min_valid, R0 + 1, 2, seed)
+    x[np.arange(R0)[None, :] >= n0[:, None]] = 0.0
+    return x
+
+
+def make_ctrl(B, L, R, D, seed=0):
+    """(B, L, R, D) fp32 >= 0; per (image, slot) the first n in [1, R] rows are non-zero."""
+    u = hash_u01(B * L * R * D, 3, seed).reshape(B, L, R, D)
+    x = _sparse_relu(u)
+    n = hash_int(B * L, 1, R + 1, 4, seed).reshape(B, L)
+    x[np.arange(R)[None, None, :] >= n[:, :, None]] = 0.0
+    return x
+
+
+def make_verbs(B, L, n_verbs, seed=0, p=0.15):
+    """(B, L) float64 (as eval_coco.py:240 builds it): -1 = no verb, else a verb id in [0, n_verbs)."""
+    u = hash_u01(B * L, 5, seed).reshape(B, L)
+    ids = hash_int(B * L, 0, n_verbs, 6, seed).reshape(B, L)
+    v = np.where(u < p, ids, -1).astype(np.float64)
+    return v
+
+
+def make_captions(B, T, V, seed=0):
+    return hash_int(B * T, 0, V, 7, seed).reshape(B, T)
+
+
+def make_gate_gts(B, T, seed=0):
+    """(B, T) in {0,1} with a trailing run of -1 padding (train.py:109 uses ignore_index=-1)."""
+    g = hash_int(B * T, 0, 2, 8, seed).reshape(B, T)
+    n = hash_int(B, max(1, T // 2), T + 1, 9, seed)
+    g[np.arange(T)[None, :] >= n[:, None]] = -1
+    return g
+
+
+def make_verb_table(n_verbs, V, seed=0):
+    """dict str(verb id) -> list of vocab ids, like datasets/coco/verb_2_vob_all_refine.json.
+    Verb 0 has no entry, verb 1 an empty list, verb 2 one id, the rest 2..6 ids."""
+    table = {}
+    for v in range(n_verbs):
+        if v == 0:
+            continue
+        if v == 1:
+            table[str(v)] = []
+            continue
+        k = 1 if v == 2 else int(hash_int(1, 2, 7, 10 + v, seed)[0])
+        table[str(v)] = [int(i) for i in hash_int(k, 1, V, 1000 + v, seed)]
+    return table
