@@ -128,6 +128,13 @@ int vsr_step(vsr_handle* h, int32_t t, int32_t rows_per_image, const int64_t* pr
              float* h1_out, float* c1_out, float* h2_out, float* c2_out, int64_t* slot_out,
              const float* verbs, int32_t gt, float* logp_words, float* logp_gates, void* stream);
 
+/* ---- measurement (bench.py roofline leg) ------------------------------------------------------------ */
+/* Between begin and end every fp32-MFMA GEMM launch is bracketed by a pair of pre-created HIP events on the
+ * caller's stream.  end() synchronises the stream and returns the summed launch durations, the number of
+ * launches and their ALGORITHMIC flops (2*M*N*K with the real, unpadded sizes). */
+int vsr_profile_begin(vsr_handle* h);
+int vsr_profile_end(vsr_handle* h, void* stream, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,9 +27,9 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, "/root/reference")
-sys.path.insert(0, os.path.join(ROOT, "vsr-guided-cic_amd"))
+sys.path.insert(0, "/root/reference")                      # the reference's `models` package must win ...
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.append(os.path.join(ROOT, "vsr-guided-cic_amd"))   # ... over this repo's drop-in `models`; only vsrcap.synth is used
 
 from vsrcap import synth  # noqa: E402
 import vsr_oracle as vo  # noqa: E402
@@ -100,20 +100,23 @@ def pick_seed_and_greedy(c):
     w = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=0)
     o32 = vo.Oracle(w, c["T"], BOS, as_written=False)
     o64 = vo.Oracle(w, c["T"], BOS, as_written=False, dtype=torch.float64)
-    for seed in range(11, 40):
+    first = int(os.environ.get("GOLDEN_FIRST_SEED", "11"))
+    for seed in range(first, 60):
         det, ctrl = inputs(c, seed)
         with torch.no_grad():
             w64, g64, marg, ks, _ = o64.test(det.double(), ctrl.double(), return_trace=True)
             w32, g32 = o32.test(det, ctrl)
         mw, mg = marg[:, :, 0].min().item(), marg[:, :, 1].min().item()
         same = bool((w64 == w32).all() and (g64 == g32).all())
-        print("seed %d: min word margin %.2e, min gate margin %.2e, fp32==fp64 %s" % (seed, mw, mg, same))
-        if mw >= 2e-4 and mg >= 2e-3 and same:
+        print("seed %d: min word margin %.2e, min gate margin %.2e, fp32==fp64 %s" % (seed, mw, mg, same), flush=True)
+        if mw >= 1e-4 and mg >= 2e-3 and same:
             return seed, w, (w64, g64, marg, ks)
     raise RuntimeError("no seed with comfortable margins")
 
 
 def main():
+    """Stages are independent and resumable:  python tests/golden/make_golden.py [small] [greedy] [beam] [verbs] [sample]"""
+    stages = sys.argv[1:] or ["small", "greedy", "beam", "verbs", "sample"]
     torch.manual_seed(0)
     tmp = tempfile.mkdtemp()
     os.makedirs(os.path.join(tmp, "datasets/coco"))
@@ -126,6 +129,30 @@ def main():
         json.dump({}, open("datasets/coco/verb_2_vob.json", "w"))
 
     set_table("small")
+    if "small" in stages:
+        stage_small(cS, cW, tables)
+    set_table("full")
+    cF = cfg_full(256)
+    if "greedy" in stages:
+        stage_greedy(cF)
+    if not os.path.exists(os.path.join(HERE, "g2_greedy.npz")):
+        return
+    z = np.load(os.path.join(HERE, "g2_greedy.npz"))
+    meta = json.loads(str(z["meta"]))
+    seed, eos = meta["seed"], meta["eos"][0]
+    rw, rg = torch.from_numpy(z["words"].astype(np.int64)), torch.from_numpy(z["gates"].astype(np.int64))
+    m, w = build_ref(cF)
+    m.eval()
+    det, ctrl = inputs(cF, seed)
+    if "beam" in stages:
+        stage_beam(m, w, cF, meta, det, ctrl, rw, rg, eos)
+    if "verbs" in stages:
+        stage_verbs(m, cF, meta, det, ctrl, seed, eos, tables)
+    if "sample" in stages:
+        stage_sample(m, meta, det, ctrl)
+
+
+def stage_small(cS, cW, tables):
     mild = {k: 1.0 for k in synth.DEFAULT_GAINS}
 
     # ---------------- G1: XE forward / loss / grads
@@ -168,9 +195,9 @@ def main():
          logp_w=lw.numpy(), logp_g=lg.numpy(), h1=s1[0].numpy(), c1=s1[1].numpy(), h2=s2[0].numpy(), c2=s2[1].numpy(),
          k=k1.numpy())
 
+
+def stage_greedy(cF):
     # ---------------- G2: greedy, 256 samples, full size
-    set_table("full")
-    cF = cfg_full(256)
     seed, w, (w64, g64, marg, ks) = pick_seed_and_greedy(cF)
     m, _ = build_ref(cF)
     m.eval()
@@ -191,6 +218,8 @@ def main():
     save("g2_greedy", meta, words=rw.numpy().astype(np.int16), gates=rg.numpy().astype(np.int8),
          slots=ks.numpy().astype(np.int8), margins=marg.numpy().astype(np.float32))
 
+
+def stage_beam(m, w, cF, meta, det, ctrl, rw, rg, eos):
     # ---------------- G3: beam-5 on the same samples
     t0 = time.time()
     with torch.no_grad():
@@ -206,6 +235,8 @@ def main():
     save("g3_beam", meta, words=bw.numpy().astype(np.int16), gates=bg.numpy().astype(np.int8),
          score64=sc[:, 0].numpy(), agree64=agree.numpy())
 
+
+def stage_verbs(m, cF, meta, det, ctrl, seed, eos, tables):
     # ---------------- G4: verb-forced beam search, full size, 32 samples
     verbs = torch.from_numpy(synth.make_verbs(32, cF["L"], NV, seed=seed, p=0.15))
     v = {}
@@ -216,6 +247,8 @@ def main():
             v["gates_gt%d" % gt] = vg.numpy().astype(np.int8)
     save("g4_beam_v", dict(meta, nv=NV, verb_p=0.15, n=32, verb_table=tables["full"]), **v)
 
+
+def stage_sample(m, meta, det, ctrl):
     # ---------------- G5: sampling replay, 32 samples
     torch.manual_seed(1234)
     with torch.no_grad():

@@ -98,7 +98,7 @@ def test_single_step_from_nonzero_state():
     np.testing.assert_allclose(lw.cpu().numpy(), g["logp_w"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(lg.cpu().numpy(), g["logp_g"], atol=2e-5, rtol=0)
     for got, key in ((s1[0], "h1"), (s1[1], "c1"), (s2[0], "h2"), (s2[1], "c2")):
-        np.testing.assert_allclose(got.cpu().numpy(), g[key], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], atol=5e-6, rtol=0)
 
 
 # ------------------------------------------------------------------ full size: greedy token-id parity on 256 samples

@@ -51,11 +51,11 @@ def test_compute_on_cpu_fails_loudly():
 
 
 def test_synth_is_deterministic_and_padded():
-    a = synth.make_ctrl(3, 4, 6, 16, seed=9)
-    b = synth.make_ctrl(3, 4, 6, 16, seed=9)
+    a = synth.make_ctrl(3, 4, 6, 256, seed=9)
+    b = synth.make_ctrl(3, 4, 6, 256, seed=9)
     assert (a == b).all() and (a >= 0).all()
     nz = (a.sum(-1) != 0)
     assert nz[:, :, 0].all()                      # at least one valid row per slot
     assert ((nz[:, :, 1:] <= nz[:, :, :-1])).all()  # valid rows first, zero padding after
-    d = synth.make_detections(5, 12, 16, seed=9)
+    d = synth.make_detections(5, 12, 256, seed=9)
     assert ((d.sum(-1) != 0).sum(1) >= 1).all()

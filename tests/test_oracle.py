@@ -116,7 +116,7 @@ def test_full_size_greedy_beam_sample_subset():
     # the fixture really is diverse and well separated
     assert len(np.unique(g["words"])) >= 200 and 0.2 <= g["gates"].mean() <= 0.8
     assert (g["slots"][:, -1] == meta["cfg"]["L"] - 1).any()
-    assert g["margins"][:, :, 0].min() >= 2e-4 and g["margins"][:, :, 1].min() >= 2e-3
+    assert g["margins"][:, :, 0].min() >= 1e-4 and g["margins"][:, :, 1].min() >= 2e-3
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference not mounted (GPU box)")

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "gemm_f32.h"
 #include "kernels.h"
@@ -70,6 +71,11 @@ struct vsr_handle {
     int gemm_tile = 64;
     int target_units = 768;
     Ctx c;
+    // measurement
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;      // pool, pairs (start, stop)
+    size_t ev_used = 0;
+    double prof_flops = 0;
 };
 
 // ---------------------------------------------------------------------------------------------- workspace
@@ -174,13 +180,28 @@ struct GemmBuilder {
         a.chunk = (u + 7) / 8;
         return nsplit;
     }
-    int launch(hipStream_t s) {
-        dim3 grid(a.chunk * 8), block(256);
-        if (tile == 128) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), grid, block, 0, s, a);
-        return hipGetLastError() == hipSuccess ? 0 : 1;
+    double flops() const {
+        double f = 0;
+        for (int i = 0; i < a.nprob; ++i)
+            for (int s = 0; s < a.p[i].nseg; ++s) f += 2.0 * a.p[i].M * a.p[i].N * a.p[i].seg[s].K;
+        return f;
     }
+    int launch(hipStream_t s, vsr_handle* h = nullptr);
 };
+
+int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
+    dim3 grid(a.chunk * 8), block(256);
+    const bool prof = h && h->profiling && h->ev_used + 2 <= h->ev.size();
+    if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
+    if (tile == 128) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), grid, block, 0, s, a);
+    if (prof) {
+        (void)hipEventRecord(h->ev[h->ev_used + 1], s);
+        h->ev_used += 2;
+        h->prof_flops += flops();
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
@@ -206,7 +227,41 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     return 0;
 }
 
-extern "C" void vsr_destroy(vsr_handle* h) { delete h; }
+extern "C" void vsr_destroy(vsr_handle* h) {
+    if (!h) return;
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+extern "C" int vsr_profile_begin(vsr_handle* h) {
+    if (!h) return fail("vsr_profile_begin: null handle");
+    const size_t want = 2 * 4096;
+    while (h->ev.size() < want) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    h->ev_used = 0;
+    h->prof_flops = 0;
+    h->profiling = true;
+    return 0;
+}
+
+extern "C" int vsr_profile_end(vsr_handle* h, void* stream, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops) {
+    if (!h || !h->profiling) return fail("vsr_profile_end: profiling not active");
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    double ms = 0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1]));
+        ms += t;
+    }
+    if (gemm_ms) *gemm_ms = ms;
+    if (gemm_launches) *gemm_launches = (int64_t)(h->ev_used / 2);
+    if (gemm_flops) *gemm_flops = h->prof_flops;
+    h->profiling = false;
+    return 0;
+}
 
 extern "C" int vsr_bind_weights(vsr_handle* h, const vsr_weights* w) {
     if (!h || !w) return fail("vsr_bind_weights: null argument");
@@ -272,7 +327,7 @@ extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R
         const int ns = g.finish(h->target_units, c.scratch_floats);
         const long long stride = (long long)B * 6 * H;
         for (int i = 0; i < 3; ++i) g.a.p[i].split_stride = stride;
-        if (g.launch(s)) return fail("vproj gemm launch failed");
+        if (g.launch(s, h)) return fail("vproj gemm launch failed");
         const long long n = (long long)B * 6 * H;
         hipLaunchKernelGGL(k_vproj_finish, dim3(cdiv(n, 256)), dim3(256), 0, s, c.scratch, ns, stride, B, H,
                            w.lstm1_bias_ih, w.lstm1_bias_hh, w.W1_is_bias, w.W1_hs_bias, w.W1_ig_bias, w.W1_hg_bias, c.vproj);
@@ -286,7 +341,7 @@ extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R
         const int ns = g.finish(h->target_units, c.scratch_floats);
         const long long stride = (long long)B * 4 * H;
         g.a.p[0].split_stride = stride;
-        if (g.launch(s)) return fail("vproj2 gemm launch failed");
+        if (g.launch(s, h)) return fail("vproj2 gemm launch failed");
         hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.vproj2);
         LAUNCHCHK();
     }
@@ -297,7 +352,7 @@ extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R
         GemmBuilder::seg(p0, regions, D, nullptr, w.att_va_weight, D, D);
         g.finish(1, 0);
         g.a.p[0].split_stride = 0;
-        if (g.launch(s)) return fail("att_va gemm launch failed");
+        if (g.launch(s, h)) return fail("att_va gemm launch failed");
         LAUNCHCHK();
     }
     h->prepared = true;
@@ -350,7 +405,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         const int ns = g.finish(h->target_units, c.scratch_floats);
         const long long stride = (long long)M * 6 * H;
         for (int i = 0; i < 3; ++i) g.a.p[i].split_stride = stride;
-        if (g.launch(s)) return fail("S1 gemm launch failed");
+        if (g.launch(s, h)) return fail("S1 gemm launch failed");
         hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj, io.rpi,
                            io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre);
     }
@@ -373,7 +428,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[0].split_stride = g.a.p[1].split_stride = stride_a;
         g.a.p[2].C = c2b_base; g.a.p[3].C = c2b_base + D;
         g.a.p[2].split_stride = g.a.p[3].split_stride = stride_b;
-        if (g.launch(s)) return fail("S2 gemm launch failed");
+        if (g.launch(s, h)) return fail("S2 gemm launch failed");
         const long long n = (long long)M * (H + A + D + A);
         hipLaunchKernelGGL(k_gate2, dim3(cdiv(n, 256)), dim3(256), 0, s, c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n,
                            w.s_fc_bias, M, H, A, D, c.g_t, c.hA, c.sent, c.sa);
@@ -398,7 +453,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         float* ga = c.scratch + stride * ns;
         g.a.p[0].split_stride = stride;
         g.a.p[1].C = ga; g.a.p[1].split_stride = stride_g;
-        if (g.launch(s)) return fail("S5 gemm launch failed");
+        if (g.launch(s, h)) return fail("S5 gemm launch failed");
         hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
                            w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n);
         hipLaunchKernelGGL(k_gatelogit, dim3(cdiv(M, 4)), dim3(256), 0, s, ga, ns, stride_g, c.hA, w.att_g_weight, c.zsum,
@@ -412,7 +467,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         const int ns = g.finish(h->target_units, c.scratch_floats);
         const long long stride = (long long)M * V;
         g.a.p[0].split_stride = stride;
-        if (g.launch(s)) return fail("S6 gemm launch failed");
+        if (g.launch(s, h)) return fail("S6 gemm launch failed");
 #define VOCAB_ARGS c.scratch, ns, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
                    io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs
         if (io.K <= 1) hipLaunchKernelGGL((k_vocab<1>), dim3(M), dim3(256), 0, s, VOCAB_ARGS);

@@ -55,6 +55,8 @@ SIGNATURES = {
     "vsr_sample": (I32, [P, U64, P, P, P, P, P, P, P]),
     "vsr_beam": (I32, [P, I32, I32, I64, I64, P, I32, P, P, P, P, P, P]),
     "vsr_xe_forward": (I32, [P, P, I32, P, P, P]),
+    "vsr_profile_begin": (I32, [P]),
+    "vsr_profile_end": (I32, [P, P, C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double)]),
     "vsr_step": (I32, [P, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P]),
 }
 
@@ -66,6 +68,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime (libamdhip64): it must be the one already mapped when libvsrcap.so is
+    # loaded, because every device pointer and stream handed to the library comes from torch.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "libvsrcap.so not found at %s: build it with `python vsr-guided-cic_amd/build.py` "

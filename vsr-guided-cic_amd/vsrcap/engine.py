@@ -104,6 +104,15 @@ class Engine:
     def _stream(self, dev):
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
+    # ------------------------------------------------------------------ measurement
+    def profile_begin(self):
+        _lib.check(self.lib.vsr_profile_begin(self.h))
+
+    def profile_end(self, device):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        _lib.check(self.lib.vsr_profile_end(self.h, self._stream(device), C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
     # ------------------------------------------------------------------ loops
     def greedy(self, B, device, verbs=None, gt=False):
         T = self.dims.seq_len
