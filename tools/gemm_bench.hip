@@ -1,0 +1,260 @@
+// Standalone check + timing of the grouped fp32-MFMA GEMM (vsr-guided-cic_amd/csrc/gemm_f32.h) on the shapes
+// of one beam-5 / greedy decoder timestep.  Build & run on the GPU box:
+//   hipcc -O3 --offload-arch=gfx950 -std=c++17 -o /tmp/gemm_bench tools/gemm_bench.hip && /tmp/gemm_bench [M] [tile] [units]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
+
+using namespace vsr;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+static float* dev_rand(size_t n, unsigned seed) {
+    std::vector<float> h(n);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
+    float* d;
+    CK(hipMalloc(&d, n * sizeof(float)));
+    CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+
+struct Builder {
+    GemmArgs a;
+    int slots, min_iters, tm, tn;
+    Builder(int slots_, int min_iters_, int tm_ = 1, int tn_ = 1) : slots(slots_), min_iters(min_iters_), tm(tm_), tn(tn_) { memset(&a, 0, sizeof(a)); }
+    GemmProb& prob(int M, int N, float* C, int ldc) { GemmProb& p = a.p[a.nprob++]; p.M = M; p.N = N; p.C = C; p.ldc = ldc; return p; }
+    static void seg(GemmProb& p, const float* A, int lda, const int* idx, const float* W, int ldw, int K) {
+        GemmSeg& s = p.seg[p.nseg++]; s.A = A; s.lda = lda; s.a_idx = idx; s.W = W; s.ldw = ldw; s.K = K;
+    }
+    int finish() {
+        int ns = gemm_plan(a, slots, min_iters, 64 * tm, 64 * tn);
+        for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
+        return ns;
+    }
+    double flops() const { return gemm_flops(a); }
+    void launch(hipStream_t st) {
+        dim3 g(((a.G + 7) / 8) * 8), b(256);
+        if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 1>), g, b, 0, st, a);
+    }
+};
+
+static double time_it(Builder& b, int reps) {
+#if defined(GEMM_STAMP)
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) CK(hipMalloc(&dbg, 4096 * 32));
+    b.a.dbg = dbg;
+#endif
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) b.launch(0);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) b.launch(0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+#if defined(GEMM_STAMP)
+    {
+        std::vector<unsigned long long> h(4 * b.a.G);
+        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double cyc = 0, ticks = 0;
+        unsigned long long s0 = ~0ull, s1 = 0, e0_ = ~0ull, e1_ = 0; double lmin = 1e30, lmax = 0;
+        int xcnt[16] = {0};
+        for (int i = 0; i < b.a.G; ++i) {
+            cyc += h[4 * i]; ticks += h[4 * i + 1];
+            unsigned long long st = h[4 * i + 2], en = st + h[4 * i + 1];
+            if (st < s0) s0 = st; if (st > s1) s1 = st; if (en < e0_) e0_ = en; if (en > e1_) e1_ = en;
+            if (h[4 * i + 1] < lmin) lmin = h[4 * i + 1]; if (h[4 * i + 1] > lmax) lmax = h[4 * i + 1];
+            xcnt[h[4 * i + 3] & 15]++;
+        }
+        printf("    clock %.0f MHz, lifetime mean %.1f min %.1f max %.1f us; starts span %.1f us, ends span %.1f us, first start->last end %.1f us; kernel %.1f us; xcc",
+               cyc / ticks * 100.0, ticks / b.a.G / 100.0, lmin / 100.0, lmax / 100.0, (s1 - s0) / 100.0, (e1_ - e0_) / 100.0, (e1_ - s0) / 100.0, ms / reps * 1e3);
+        for (int i = 0; i < 8; ++i) printf(" %d", xcnt[i]);
+        printf("\n");
+        if (getenv("GEMM_DUMP")) {
+            double xs[8] = {0}; int xn[8] = {0};
+            for (int i = 0; i < b.a.G; ++i) { xs[h[4 * i + 3] & 7] += h[4 * i + 1] / 100.0; xn[h[4 * i + 3] & 7]++; }
+            printf("    mean lifetime per XCC:"); for (int i = 0; i < 8; ++i) printf(" %.1f", xs[i] / (xn[i] ? xn[i] : 1)); printf("\n");
+            printf("    lifetime by g (every 16th):"); for (int i = 0; i < b.a.G; i += 16) printf(" %.0f", h[4 * i + 1] / 100.0); printf("\n");
+        }
+    }
+#endif
+    return ms / reps;
+}
+
+// register-only MFMA loop: what the matrix pipe sustains on this box (and the clock it holds: guide 'DVFS give-back' 6)
+__global__ __launch_bounds__(256) void mfma_peak(float* out, int iters, unsigned long long* clk) {
+    f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+    float x = threadIdx.x * 1e-3f, y = blockIdx.x * 1e-4f + 0.5f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int e = 0; e < 16; ++e) s += a0[e] + a1[e] + a2[e] + a3[e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
+// one dependent accumulator chain per wave, operands re-read from LDS each 16 MFMAs (the GEMM's inner loop shape)
+template <int LDSREAD>
+__global__ __launch_bounds__(256) void mfma_chain(float* out, int iters) {
+    __shared__ float sm[128 * 36];
+    for (int i = threadIdx.x; i < 128 * 36; i += 256) sm[i] = i * 1e-4f;
+    __syncthreads();
+    f32x16 a0 = {0};
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5, wave = threadIdx.x >> 6;
+    const float* ab = sm + ((wave >> 1) * 32 + r) * 36 + 4 * hh;
+    const float* bb = sm + (64 + (wave & 1) * 32 + r) * 36 + 4 * hh;
+    float4 av[4], bv[4];
+    for (int kk = 0; kk < 4; ++kk) { av[kk] = *(const float4*)(ab + kk * 8); bv[kk] = *(const float4*)(bb + kk * 8); }
+    for (int i = 0; i < iters; ++i) {
+        if (LDSREAD) {
+            int off = 0;
+            asm volatile("" : "+v"(off));          // opaque: forces the reads to be re-issued every iteration
+            for (int kk = 0; kk < 4; ++kk) { av[kk] = *(const float4*)(ab + off + kk * 8); bv[kk] = *(const float4*)(bb + off + kk * 8); }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk].x, bv[kk].x, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk].y, bv[kk].y, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk].z, bv[kk].z, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk].w, bv[kk].w, a0, 0, 0, 0);
+        }
+        if (LDSREAD == 2) __syncthreads();
+    }
+    float s = 0;
+    for (int e = 0; e < 16; ++e) s += a0[e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "chain")) {
+        float* o; CK(hipMalloc(&o, 4096 * 256 * 4));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int mode = 0; mode < 3; ++mode)
+            for (int mult = 1; mult <= 4; mult *= 2) {
+                const int blocks = 256 * mult, iters = argc > 2 ? atoi(argv[2]) : 2000;
+                for (int rep = 0; rep < 2; ++rep) {
+                    CK(hipEventRecord(e0, 0));
+                    if (mode == 0) hipLaunchKernelGGL(mfma_chain<0>, dim3(blocks), dim3(256), 0, 0, o, iters);
+                    else if (mode == 1) hipLaunchKernelGGL(mfma_chain<1>, dim3(blocks), dim3(256), 0, 0, o, iters);
+                    else hipLaunchKernelGGL(mfma_chain<2>, dim3(blocks), dim3(256), 0, 0, o, iters);
+                    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                }
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("chain mode %d (0 regs, 1 +ds_read, 2 +barrier) %d waves/SIMD: %.1f TF/s\n", mode, mult, (double)blocks * 4 * iters * 16 * 4096.0 / ms / 1e9);
+            }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "peak")) {
+        const int blocks = 256 * (argc > 2 ? atoi(argv[2]) : 1), iters = 20000;
+        float* o; unsigned long long* clk; CK(hipMalloc(&o, blocks * 256 * 4)); CK(hipMalloc(&clk, blocks * 16));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(mfma_peak, dim3(blocks), dim3(256), 0, 0, o, iters, clk);
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(mfma_peak, dim3(blocks), dim3(256), 0, 0, o, iters, clk);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        std::vector<unsigned long long> h(blocks * 2); CK(hipMemcpy(h.data(), clk, blocks * 16, hipMemcpyDeviceToHost));
+        double fl = (double)blocks * 4 * iters * 4 * 4096.0;
+        printf("mfma_peak: %d blocks, %.3f ms, %.1f TF/s, in-kernel clock %.0f MHz\n", blocks, ms, fl / ms / 1e9, (double)h[0] / h[1] * 100.0);
+        return 0;
+    }
+    const int M = argc > 1 ? atoi(argv[1]) : 500;
+    const int slots = argc > 2 ? atoi(argv[2]) : 1024, min_iters = argc > 3 ? atoi(argv[3]) : 8;
+    const int tm = argc > 4 ? atoi(argv[4]) : 1, tn = argc > 5 ? atoi(argv[5]) : 1;
+    const int H = 1000, E = 1000, D = 2048, A = 512, V = 10000, in1 = 4048, in2 = 3048;
+
+    // ---- correctness on a ragged problem: gather index, 3 segments with K tails, split-K, column window
+    {
+        const int m = 77, n = 150, k1 = 72, k2 = 40, k3 = 100, ldw = 260, nrowsA = 200;
+        float* A1 = dev_rand((size_t)nrowsA * k1, 1); float* A2 = dev_rand((size_t)nrowsA * k2, 2); float* A3 = dev_rand((size_t)m * k3, 3);
+        float* W = dev_rand((size_t)n * ldw, 4);
+        std::vector<int> hidx(m); for (int i = 0; i < m; ++i) hidx[i] = (i * 37 + 11) % nrowsA;
+        int* idx; CK(hipMalloc(&idx, m * sizeof(int))); CK(hipMemcpy(idx, hidx.data(), m * sizeof(int), hipMemcpyHostToDevice));
+        float* C; CK(hipMalloc(&C, (size_t)8 * m * 160 * sizeof(float))); CK(hipMemset(C, 0, (size_t)8 * m * 160 * sizeof(float)));
+        Builder b(slots, min_iters, tm, tn);
+        GemmProb& p = b.prob(m, n, C + 5, 160);
+        Builder::seg(p, A1, k1, idx, W, ldw, k1); Builder::seg(p, A2, k2, idx, W + k1, ldw, k2); Builder::seg(p, A3, k3, nullptr, W + k1 + k2, ldw, k3);
+        int ns = b.finish();
+        b.launch(0); CK(hipDeviceSynchronize());
+        std::vector<float> hC((size_t)ns * m * 160), hA1((size_t)nrowsA * k1), hA2((size_t)nrowsA * k2), hA3((size_t)m * k3), hW((size_t)n * ldw);
+        CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hA1.data(), A1, hA1.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hA2.data(), A2, hA2.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hA3.data(), A3, hA3.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hW.data(), W, hW.size() * 4, hipMemcpyDeviceToHost));
+        double maxerr = 0;
+        for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) {
+            double ref = 0;
+            for (int k = 0; k < k1; ++k) ref += (double)hA1[(size_t)hidx[i] * k1 + k] * hW[(size_t)j * ldw + k];
+            for (int k = 0; k < k2; ++k) ref += (double)hA2[(size_t)hidx[i] * k2 + k] * hW[(size_t)j * ldw + k1 + k];
+            for (int k = 0; k < k3; ++k) ref += (double)hA3[(size_t)i * k3 + k] * hW[(size_t)j * ldw + k1 + k2 + k];
+            double got = 0;
+            for (int s = 0; s < ns; ++s) got += hC[(size_t)s * m * 160 + (size_t)i * 160 + 5 + j];
+            maxerr = fmax(maxerr, fabs(got - ref));
+        }
+        printf("correctness (G %d, nslab %d): max |err| = %.3g %s\n", b.a.G, ns, maxerr, maxerr < 1e-4 ? "OK" : "FAIL");
+        if (maxerr >= 1e-4 && !GEMM_ABLATE && !getenv("GEMM_NOCHECK")) return 1;
+    }
+
+    // ---- timing on the decoder shapes
+    float* h2 = dev_rand((size_t)M * H, 5); float* h1 = dev_rand((size_t)M * H, 6); float* att = dev_rand((size_t)M * D, 7);
+    float* emb = dev_rand((size_t)V * E, 8);
+    float* Wih1 = dev_rand((size_t)4 * H * in1, 9); float* Whh1 = dev_rand((size_t)4 * H * H, 10);
+    float* Wis = dev_rand((size_t)H * in1, 11); float* Whs = dev_rand((size_t)H * H, 12); float* Wig = dev_rand((size_t)H * in1, 13);
+    float* Wih2 = dev_rand((size_t)4 * H * in2, 14); float* Whh2 = dev_rand((size_t)4 * H * H, 15);
+    float* Wout = dev_rand((size_t)V * H, 16); float* Wsfc = dev_rand((size_t)D * H, 17); float* Wa = dev_rand((size_t)A * H, 18);
+    std::vector<int> hw(M), hp(M);
+    for (int i = 0; i < M; ++i) { hw[i] = (i * 7919 + 13) % V; hp[i] = (i / 5) * 5 + (i * 3) % 5; if (hp[i] >= M) hp[i] = i; }
+    int *widx, *pidx; CK(hipMalloc(&widx, M * 4)); CK(hipMalloc(&pidx, M * 4));
+    CK(hipMemcpy(widx, hw.data(), M * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(pidx, hp.data(), M * 4, hipMemcpyHostToDevice));
+    float* C; CK(hipMalloc(&C, (size_t)8 * M * V * sizeof(float)));
+    double tot_ms = 0, tot_fl = 0;
+    {
+        Builder b(slots, min_iters, tm, tn);
+        const float* Wi[3] = {Wih1, Wis, Wig}; const float* Wh[3] = {Whh1, Whs, nullptr}; const int N[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
+        for (int i = 0; i < 3; ++i) {
+            GemmProb& p = b.prob(M, N[i], C + off[i], 6 * H);
+            Builder::seg(p, h2, H, pidx, Wi[i], in1, H); Builder::seg(p, emb, E, widx, Wi[i] + H + D, in1, E);
+            if (Wh[i]) Builder::seg(p, h1, H, pidx, Wh[i], H, H);
+        }
+        int ns = b.finish(); double ms = time_it(b, 20);
+        printf("S1  nslab %d G %5d  %8.1f us  %6.1f TF/s\n", ns, b.a.G, ms * 1e3, b.flops() / ms / 1e9); tot_ms += ms; tot_fl += b.flops();
+    }
+    {
+        Builder b(slots, min_iters, tm, tn);
+        GemmProb& p0 = b.prob(M, H, C, H + A); Builder::seg(p0, h1, H, nullptr, Whs, H, H);
+        GemmProb& p1 = b.prob(M, A, C + H, H + A); Builder::seg(p1, h1, H, nullptr, Wa, H, H);
+        GemmProb& p2 = b.prob(M, D, C + 8 * M * (H + A), D + A); Builder::seg(p2, h2, H, nullptr, Wsfc, H, H);
+        GemmProb& p3 = b.prob(M, A, C + 8 * M * (H + A) + D, D + A); Builder::seg(p3, h2, H, nullptr, Wa, H, H);
+        int ns = b.finish(); double ms = time_it(b, 20);
+        printf("S2  nslab %d G %5d  %8.1f us  %6.1f TF/s\n", ns, b.a.G, ms * 1e3, b.flops() / ms / 1e9); tot_ms += ms; tot_fl += b.flops();
+    }
+    {
+        Builder b(slots, min_iters, tm, tn);
+        GemmProb& p0 = b.prob(M, 4 * H, C, 4 * H);
+        Builder::seg(p0, h1, H, nullptr, Wih2, in2, H); Builder::seg(p0, att, D, nullptr, Wih2 + H, in2, D); Builder::seg(p0, h2, H, pidx, Whh2, H, H);
+        GemmProb& p1 = b.prob(M, A, C + 8 * M * 4 * H, A); Builder::seg(p1, h1, H, nullptr, Wa, H, H);
+        int ns = b.finish(); double ms = time_it(b, 20);
+        printf("S5  nslab %d G %5d  %8.1f us  %6.1f TF/s\n", ns, b.a.G, ms * 1e3, b.flops() / ms / 1e9); tot_ms += ms; tot_fl += b.flops();
+    }
+    {
+        Builder b(slots, min_iters, tm, tn);
+        GemmProb& p0 = b.prob(M, V, C, V); Builder::seg(p0, h2, H, nullptr, Wout, H, H);
+        int ns = b.finish(); double ms = time_it(b, 20);
+        printf("S6  nslab %d G %5d  %8.1f us  %6.1f TF/s\n", ns, b.a.G, ms * 1e3, b.flops() / ms / 1e9); tot_ms += ms; tot_fl += b.flops();
+    }
+    printf("step GEMMs M=%d slots %d min_iters %d tile %dx%d: %.1f us, %.1f TF/s\n", M, slots, min_iters, 64 * tm, 64 * tn, tot_ms * 1e3, tot_fl / tot_ms / 1e9);
+    return 0;
+}

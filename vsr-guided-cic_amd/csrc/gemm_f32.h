@@ -1,19 +1,28 @@
 // Grouped "NT" fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
 //
-//   C_p[s][m][n] = sum over the k-tiles of split s, over segments g:  A_pg[row_g(m)][k] * W_pg[n][k]
+//   C_p[m][n] = sum over segments g, k:  A_pg[row_g(m)][k] * W_pg[n][k]        (returned as S partial slabs)
 //
 // A launch carries up to 4 independent problems (e.g. h1 -> [W1_hg | att_ha] and s_t -> [s_fc | att_sa]);
 // each problem sums up to 3 K-segments so that the reference's torch.cat([h2, vbar, x]) (step :147, :176)
 // is never materialised: every segment reads its own activation matrix and a column window of the
 // reference-layout [out, in] weight, in place.  Activation rows may be gathered through an int32 index
-// (embedding rows, beam parents).  Split-K slabs are summed by the consumer kernels.
+// (embedding rows, beam parents).
 //
-// Tile: BM x BN x 32, 256 threads = 4 waves (2 x 2), each wave (BM/64) x (BN/64) MFMA tiles of 32x32.
+// Decomposition: STREAM-K.  The decoder GEMMs are skinny (M = 100..500 rows against N = 512..10000), so a
+// tile-per-workgroup grid leaves the last round of workgroups mostly idle (measured: 2272 tiles on 1024
+// resident slots = 74 % of the achievable rate).  Instead the launch has G resident workgroups and the
+// linearised iteration space  sum_p tiles_p * ktiles_p  (one iteration = one 64x64x32 MFMA step) is cut into G
+// equal contiguous ranges.  A range that ends inside a tile leaves a partial sum; every tile therefore has
+// between 1 and S pieces, piece j goes to slab j and the workgroup that finishes the tile zero-fills the slabs
+// it did not use.  Consumers add the S slabs in index order: deterministic, no atomics, no inter-workgroup
+// synchronisation, no memset.
+//
+// Tile: 64 x 64 x 32, 256 threads = 4 waves (2 x 2), one 32x32 accumulator per wave.
 // LDS rows are padded to 36 floats: ds_write_b128 / ds_read_b128 are bank-conflict free (guide LDS table).
 // Lane (r = lane & 31, h = lane >> 5) reads A[r][8*kk + 4h .. +3] with one ds_read_b128 and feeds the four
 // floats to four MFMAs; A and B use the same k permutation, so the sum is unchanged.
-// Work units are dealt so that all m-tiles of one weight n-tile run on ONE XCD back to back: the weight
-// tile is fetched from HBM once and re-read from that XCD's L2.
+// Workgroup ranges are dealt XCD-contiguously (blocks b and b+8 share an XCD), so the m-tiles of one weight
+// n-tile run on one XCD back to back and the weight tile is fetched from HBM once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,93 +43,120 @@ struct GemmSeg {
 
 struct GemmProb {
     GemmSeg seg[3];
-    float* C;            // (nsplit, M, ldc)
-    long long split_stride;
+    float* C;            // (nslab, M, ldc)
+    long long slab_stride;
     int nseg;
     int M;
     int N;
     int ldc;
-    int nsplit;
     int tiles_m;
     int tiles_n;
-    int unit_begin;      // first work unit of this problem in the launch
-    int ktiles;          // total 32-wide k-tiles over all segments
-    int pad_;
+    int ktiles;          // 32-wide k-tiles over all segments
+    int it_begin;        // first global iteration of this problem
 };
 
 struct GemmArgs {
     GemmProb p[4];
     int nprob;
-    int total_units;
-    int chunk;           // ceil(total_units / 8): units per XCD
-    int pad_;
+    int total_iters;
+    int G;               // workgroups with a non-empty range (1 <= G <= total_iters); grid = 8 * ceil(G / 8)
+    int nslab;           // slabs per tile (S)
+    unsigned long long* dbg;   // diagnostics build only (GEMM_STAMP): per-workgroup {shader cycles, 100 MHz ticks}
 };
 
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0    // diagnostics only (tools/gemm_bench.hip): 1 = no global loads in the loop, 2 = also no LDS refill
+#endif
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LDS = GEMM_BK + 4;
 
-template <int BM, int BN>
+__device__ __host__ inline int gemm_range_begin(int g, int total, int G) { return (int)(((long long)g * total) / G); }
+
+template <int TM, int TN>      // 32x32 MFMA tiles per wave; workgroup tile = (64 TM) x (64 TN)
 __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs args) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int LA = BM / 32, LB = BN / 32;            // float4 loads per thread per k-tile
     __shared__ float smem[2 * (BM + BN) * GEMM_LDS];
     auto sA = [&](int buf) { return smem + buf * (BM + BN) * GEMM_LDS; };
     auto sB = [&](int buf) { return smem + buf * (BM + BN) * GEMM_LDS + BM * GEMM_LDS; };
 
-    // ---- work unit (XCD-contiguous dealing: blocks b and b+8 share an XCD)
-    const int bid = blockIdx.x;
-    const int unit = (bid & 7) * args.chunk + (bid >> 3);
-    if (unit >= args.total_units) return;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-        if (i < args.nprob && unit >= args.p[i].unit_begin) pi = i;
-    const GemmProb& P = args.p[pi];
-    int lu = unit - P.unit_begin;
-    const int mt = lu % P.tiles_m;
-    lu /= P.tiles_m;
-    const int nt = lu % P.tiles_n;
-    const int split = lu / P.tiles_n;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int kt_begin = (int)(((long long)P.ktiles * split) / P.nsplit);
-    const int kt_end = (int)(((long long)P.ktiles * (split + 1)) / P.nsplit);
+    const int G = args.G;
+    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);      // grid = 8 * ceil(G / 8)
+    if (g >= G) return;
+    const int it0 = gemm_range_begin(g, args.total_iters, G);
+    const int it1 = gemm_range_begin(g + 1, args.total_iters, G);
+    if (it0 >= it1) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
-
-    // ---- per-thread load coordinates (8 threads cover one 128-byte row segment)
-    const int lrow = tid >> 3;          // 0..31
+    const int lrow = tid >> 3;          // 0..31: 8 threads cover one 128-byte row segment
     const int lc4 = (tid & 7) * 4;      // float offset inside the k-tile
+
+    // ------------------------------------------------------------------ load cursor (runs one iteration ahead)
     float4 ra[LA], rb[LB];
-
-    // running segment cursor
-    int seg = 0, seg_kt0 = 0;           // first k-tile index of the current segment
-    auto seg_tiles = [&](int s) { return (P.seg[s].K + GEMM_BK - 1) / GEMM_BK; };
-    {
-        int kt = kt_begin;
-        while (seg < P.nseg - 1 && kt >= seg_kt0 + seg_tiles(seg)) { seg_kt0 += seg_tiles(seg); ++seg; }
-    }
-
-    auto load_tile = [&](int kt) {
-        while (seg < P.nseg - 1 && kt >= seg_kt0 + seg_tiles(seg)) { seg_kt0 += seg_tiles(seg); ++seg; }
-        const GemmSeg& S = P.seg[seg];
-        const int k = (kt - seg_kt0) * GEMM_BK + lc4;
-        const bool kin = k < S.K;
+    const float* pa[LA];
+    const float* pb[LB];
+    int l_prob = 0, l_tile = 0, l_tile_left = 0;          // problem, local tile id, k-tiles left in the tile
+    int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;      // segment, k-tiles left in it, next k, its K
+    auto open_segment = [&](int s, int first_tile) {
+        const GemmProb& P = args.p[l_prob];
+        const GemmSeg& S = P.seg[s];
+        const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
+        l_seg = s;
+        l_K = S.K;
+        l_k = first_tile * GEMM_BK;
+        l_seg_left = (S.K + GEMM_BK - 1) / GEMM_BK - first_tile;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             int m = m0 + lrow + 32 * i;
             m = m < P.M ? m : P.M - 1;
             const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
-            ra[i] = kin ? *reinterpret_cast<const float4*>(S.A + row * S.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pa[i] = S.A + row * S.lda + lc4;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             int n = n0 + lrow + 32 * i;
             n = n < P.N ? n : P.N - 1;
-            rb[i] = kin ? *reinterpret_cast<const float4*>(S.W + (long long)n * S.ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[i] = S.W + (long long)n * S.ldw + lc4;
         }
+    };
+    auto open_tile = [&](int prob, int tile, int kt) {     // position the cursor on k-tile kt of a tile
+        l_prob = prob;
+        l_tile = tile;
+        const GemmProb& P = args.p[prob];
+        l_tile_left = P.ktiles - kt;
+        int s = 0;
+        while (s < P.nseg - 1 && kt >= (P.seg[s].K + GEMM_BK - 1) / GEMM_BK) { kt -= (P.seg[s].K + GEMM_BK - 1) / GEMM_BK; ++s; }
+        open_segment(s, kt);
+    };
+    auto load_next = [&]() {
+        if (l_tile_left == 0) {                            // wave-uniform, once per tile
+            if (l_tile + 1 < args.p[l_prob].tiles_m * args.p[l_prob].tiles_n) open_tile(l_prob, l_tile + 1, 0);
+            else open_tile(l_prob + 1, 0, 0);
+        } else if (l_seg_left == 0) {
+            open_segment(l_seg + 1, 0);
+        }
+        const bool kin = l_k + lc4 < l_K;                  // K tail: read a valid address, use zeros
+#if defined(GEMM_L1HOT)
+        const int ko = 0;                                  // diagnostics: every k-tile re-reads the same (L1-resident) lines
+#else
+        const int ko = kin ? l_k : 0;
+#endif
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(pa[i] + ko);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const float4*>(pb[i] + ko);
+        if (!kin) {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < LB; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        l_k += GEMM_BK;
+        --l_seg_left;
+        --l_tile_left;
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -131,24 +167,105 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs args) {
             *reinterpret_cast<float4*>(sB(buf) + (lrow + 32 * i) * GEMM_LDS + lc4) = rb[i];
     };
 
-    f32x16 acc[TM][TN];
+    // ------------------------------------------------------------------ compute-side tile bookkeeping
+    int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0;   // iterations left before this tile's piece is flushed
+    bool c_last = false;                                   // this piece completes the tile
+    auto decode = [&](int it) {                            // global iteration -> tile, piece, #iterations here
+        int p = 0;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int i = 1; i < 4; ++i)
+            if (i < args.nprob && it >= args.p[i].it_begin) p = i;
+        const GemmProb& P = args.p[p];
+        const int local = it - P.it_begin;
+        c_prob = p;
+        c_tile = local / P.ktiles;
+        const int kt = local - c_tile * P.ktiles;
+        const int tile_base = it - kt;
+        // first workgroup whose range contains the tile's first iteration
+        const int g_first = (int)((((long long)tile_base + 1) * G - 1) / args.total_iters);
+        c_piece = g - g_first;
+        const int rem = P.ktiles - kt;
+        c_left = rem < it1 - it ? rem : it1 - it;
+        c_last = (c_left == rem);
+        return kt;
+    };
 
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-        __syncthreads();
-        int cur = 0;
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const bool more = kt + 1 < kt_end;
-            if (more) load_tile(kt + 1);                 // global -> registers, in flight during the MFMAs
-            const float* a_base = sA(cur) + (wm * (BM / 2) + r) * GEMM_LDS + 4 * hh;
-            const float* b_base = sB(cur) + (wn * (BN / 2) + r) * GEMM_LDS + 4 * hh;
+    // Epilogue of one tile piece.  The accumulator (C/D layout: col = lane & 31, row = (e & 3) + 8 (e >> 2) +
+    // 4 (lane >> 5)) is transposed through the LDS buffer the k loop has just finished with, so that the tile
+    // leaves as 4 x 16-byte stores per thread (full 256-byte rows) instead of 16 dword stores with per-element
+    // address arithmetic; unused slabs of a finished tile get zeros the same way.
+    constexpr int ST_LD = BN + 4;
+    auto flush = [&](const f32x16 (&acc)[TM][TN], float* stage) {
+        const GemmProb& P = args.p[c_prob];
+        const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
+        float* C = P.C + (long long)c_piece * P.slab_stride;
+        const int extra = c_last ? args.nslab - 1 - c_piece : 0;     // unused slabs of a finished tile: zeros
+        const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
+        constexpr int TPR = BN / 4;                        // threads per staged row
+        constexpr int RPP = 256 / TPR;                     // rows per store pass
+        const int c4 = (tid % TPR) * 4;
+        const int n = n0 + c4;
+#pragma unroll
+        for (int ti = 0; ti < TM; ++ti) {                  // one 64-row band per pass (rows wm*32.. of tile-row ti)
+#pragma unroll
+            for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    stage[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 64 / RPP; ++i) {
+                const int sr = tid / TPR + RPP * i;        // staged row 0..63
+                const int m = m0 + (sr >> 5) * (32 * TM) + ti * 32 + (sr & 31);
+                if (m < P.M && n < P.N) {
+                    const float4 v = *reinterpret_cast<const float4*>(stage + sr * ST_LD + c4);
+                    float* dst = C + (long long)m * P.ldc + n;
+                    if (vec_ok && n + 3 < P.N) {
+                        *reinterpret_cast<float4*>(dst) = v;
+                        for (int x = 1; x <= extra; ++x)
+                            *reinterpret_cast<float4*>(dst + (long long)x * P.slab_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < P.N) {
+                                dst[q] = vv[q];
+                                for (int x = 1; x <= extra; ++x) dst[(long long)x * P.slab_stride + q] = 0.f;
+                            }
+                    }
+                }
+            }
+            __syncthreads();                               // the next pass / store_tile() overwrites `stage`
+        }
+    };
+
+#if defined(GEMM_STAMP)
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    {
+        const int kt = decode(it0);
+        open_tile(c_prob, c_tile, kt);
+    }
+    load_next();
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    // Outer loop: one tile piece; inner loop: its k iterations.  The accumulator is only ever touched by MFMAs
+    // inside the inner loop, so it stays in the accumulator registers (a VALU read/zero of it inside the k loop
+    // made hipcc shuttle all 16 registers through v_accvgpr_read/write and drain the MFMA pipe every iteration).
+    for (int it = it0; it < it1;) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int n_it = c_left;
+        for (int j_it = 0; j_it < n_it; ++j_it, ++it) {
+            const bool more = it + 1 < it1;
+            if (more && GEMM_ABLATE < 1) load_next();      // global -> registers, in flight during the MFMAs
+            const float* a_base = sA(cur) + (wm * (32 * TM) + r) * GEMM_LDS + 4 * hh;
+            const float* b_base = sB(cur) + (wn * (32 * TN) + r) * GEMM_LDS + 4 * hh;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 float4 av[TM], bv[TN];
@@ -166,27 +283,62 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs args) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
                     }
             }
-            if (more) {
-                store_tile(cur ^ 1);                     // other buffer: nobody reads it in this iteration
+            if (more && GEMM_ABLATE < 2) {
+                store_tile(cur ^ 1);                       // other buffer: nobody reads it in this iteration
                 __syncthreads();
                 cur ^= 1;
             }
         }
+        if (GEMM_ABLATE < 3) flush(acc, sA(cur ^ 1));
+        else asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15]));
+        if (it < it1) decode(it);
     }
+#if defined(GEMM_STAMP)
+    if (args.dbg && tid == 0) {
+        args.dbg[4 * g] = __builtin_amdgcn_s_memtime() - st0;
+        args.dbg[4 * g + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
+        args.dbg[4 * g + 2] = sr0;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        args.dbg[4 * g + 3] = xcc;
+    }
+#endif
+}
 
-    // ---- epilogue: raw partial sums; C/D layout col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-    float* C = P.C + (long long)split * P.split_stride;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 32 + r;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (m < P.M && n < P.N) C[(long long)m * P.ldc + n] = acc[i][j][e];
-            }
-        }
+// Host side: fill tiles / iteration offsets, pick the number of workgroups and the slab count.
+//   slots      resident workgroups the launch should fill (CUs x 4 for this 36.9 KB-LDS kernel)
+//   min_iters  smallest range worth a workgroup (prologue + flush amortisation)
+// Returns nslab; the caller then sets every problem's C / slab_stride (slabs are nslab deep).
+inline int gemm_plan(GemmArgs& a, int slots, int min_iters = 8, int BM = 64, int BN = 64) {
+    int total = 0, kt_max = 1;
+    for (int i = 0; i < a.nprob; ++i) {
+        GemmProb& p = a.p[i];
+        p.tiles_m = (p.M + BM - 1) / BM;
+        p.tiles_n = (p.N + BN - 1) / BN;
+        p.ktiles = 0;
+        for (int s = 0; s < p.nseg; ++s) p.ktiles += (p.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+        p.it_begin = total;
+        total += p.tiles_m * p.tiles_n * p.ktiles;
+        if (p.ktiles > kt_max) kt_max = p.ktiles;
+    }
+    a.total_iters = total;
+    int G = total / min_iters;
+    if (G > slots) G = slots;
+    const int L_min = (kt_max + 6) / 7;            // keep pieces per tile <= 8
+    if (G > total / L_min) G = total / L_min;
+    if (G < 1) G = 1;
+    a.G = G;
+    const int L = total / G;                       // shortest range
+    a.nslab = G == 1 ? 1 : (kt_max + L - 1) / L + 1;
+    if (a.nslab > 8) a.nslab = 8;
+    return a.nslab;
+}
+
+inline double gemm_flops(const GemmArgs& a) {
+    double f = 0;
+    for (int i = 0; i < a.nprob; ++i)
+        for (int s = 0; s < a.p[i].nseg; ++s) f += 2.0 * a.p[i].M * a.p[i].N * a.p[i].seg[s].K;
+    return f;
 }
 
 }  // namespace vsr

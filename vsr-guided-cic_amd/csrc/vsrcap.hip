@@ -68,8 +68,9 @@ struct vsr_handle {
     const int* vt_ptr = nullptr;
     const int* vt_ids = nullptr;
     int n_verbs = 0;
-    int gemm_tile = 64;
-    int target_units = 768;
+    int gemm_slots = 1024;       // resident 64x64 GEMM workgroups to fill: 256 CUs x 4 (36.9 KB LDS each)
+    int gemm_min_iters = 8;
+    int gemm_tile = 0;           // 0 = by M, 64 / 128 forced (VSR_GEMM_TILE)
     Ctx c;
     // measurement
     bool profiling = false;
@@ -134,7 +135,7 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     // split-K slab scratch: the widest stage, 8 slabs
     size_t widest = std::max({6 * H, (H + A) + (D + A), 4 * H + A, V});
     size_t stage = std::max(M * widest, B * 6 * H);
-    c.scratch_floats = stage * 8;
+    c.scratch_floats = std::max(stage * 8, rows * A * 8);       // att_va slabs of prepare()
     c.scratch = b.take<float>(c.scratch_floats);
     return (b.off + 255) & ~size_t(255);
 }
@@ -142,8 +143,7 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
 // ---------------------------------------------------------------------------------------------- GEMM launch
 struct GemmBuilder {
     GemmArgs a;
-    int tile;
-    GemmBuilder(int tile_) : tile(tile_) { memset(&a, 0, sizeof(a)); }
+    GemmBuilder() { memset(&a, 0, sizeof(a)); }
     GemmProb& prob(int M, int N, float* C, int ldc) {
         GemmProb& p = a.p[a.nprob++];
         p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.nseg = 0;
@@ -154,51 +154,28 @@ struct GemmBuilder {
         GemmSeg& s = p.seg[p.nseg++];
         s.A = A; s.lda = lda; s.a_idx = idx; s.W = W; s.ldw = ldw; s.K = K;
     }
-    // common split count for the launch; slabs of one problem are split_stride apart
-    int finish(int target_units, size_t max_slab_floats_total) {
-        int base = 0, min_kt = 1 << 30;
-        for (int i = 0; i < a.nprob; ++i) {
-            GemmProb& p = a.p[i];
-            p.tiles_m = (p.M + tile - 1) / tile;
-            p.tiles_n = (p.N + tile - 1) / tile;
-            p.ktiles = 0;
-            for (int s = 0; s < p.nseg; ++s) p.ktiles += (p.seg[s].K + GEMM_BK - 1) / GEMM_BK;
-            base += p.tiles_m * p.tiles_n;
-            min_kt = std::min(min_kt, p.ktiles);
-        }
-        int nsplit = (target_units + base - 1) / base;
-        nsplit = std::max(1, std::min({nsplit, 8, std::max(1, min_kt / 8)}));
-        (void)max_slab_floats_total;
-        int u = 0;
-        for (int i = 0; i < a.nprob; ++i) {
-            GemmProb& p = a.p[i];
-            p.nsplit = nsplit;
-            p.unit_begin = u;
-            u += p.tiles_m * p.tiles_n * nsplit;
-        }
-        a.total_units = u;
-        a.chunk = (u + 7) / 8;
-        return nsplit;
+    int big = 0;       // 1: 128x128 workgroup tiles (2x2 MFMA tiles per wave), 0: 64x64
+    // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
+    int finish(const vsr_handle* h) {
+        int maxM = 0;
+        for (int i = 0; i < a.nprob; ++i) maxM = std::max(maxM, a.p[i].M);
+        big = h->gemm_tile == 128 || (h->gemm_tile == 0 && maxM > 192);
+        // resident workgroups: 4 per CU at 36.9 KB LDS (64x64), 2 per CU at 73.7 KB (128x128)
+        return gemm_plan(a, big ? h->gemm_slots / 2 : h->gemm_slots, h->gemm_min_iters, big ? 128 : 64, big ? 128 : 64);
     }
-    double flops() const {
-        double f = 0;
-        for (int i = 0; i < a.nprob; ++i)
-            for (int s = 0; s < a.p[i].nseg; ++s) f += 2.0 * a.p[i].M * a.p[i].N * a.p[i].seg[s].K;
-        return f;
-    }
-    int launch(hipStream_t s, vsr_handle* h = nullptr);
+    int launch(hipStream_t s, vsr_handle* h);
 };
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
-    dim3 grid(a.chunk * 8), block(256);
-    const bool prof = h && h->profiling && h->ev_used + 2 <= h->ev.size();
+    dim3 grid(((a.G + 7) / 8) * 8), block(256);
+    const bool prof = h->profiling && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
-    if (tile == 128) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 128>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 64>), grid, block, 0, s, a);
+    if (big) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 1>), grid, block, 0, s, a);
     if (prof) {
         (void)hipEventRecord(h->ev[h->ev_used + 1], s);
         h->ev_used += 2;
-        h->prof_flops += flops();
+        h->prof_flops += gemm_flops(a);
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -221,8 +198,13 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("vsr_create: no HIP device");
     vsr_handle* h = new vsr_handle();
     h->d = d;
-    if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e) == 128 ? 128 : 64;
-    if (const char* e = getenv("VSR_GEMM_UNITS")) h->target_units = std::max(1, atoi(e));
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        h->gemm_slots = prop.multiProcessorCount * 4;
+    if (const char* e = getenv("VSR_GEMM_SLOTS")) h->gemm_slots = std::max(1, atoi(e));
+    if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e);
+    if (const char* e = getenv("VSR_GEMM_MIN_ITERS")) h->gemm_min_iters = std::max(1, atoi(e));
     *out = h;
     return 0;
 }
@@ -317,16 +299,16 @@ extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R
     const int in1 = (d.h2_first_lstm ? H : 0) + D + E;
     const int voff = d.h2_first_lstm ? H : 0;
     {
-        GemmBuilder g(h->gemm_tile);
+        GemmBuilder g;
         GemmProb& p0 = g.prob(B, 4 * H, c.scratch, 6 * H);
         GemmBuilder::seg(p0, c.vbar, D, nullptr, w.lstm1_weight_ih + voff, in1, D);
         GemmProb& p1 = g.prob(B, H, c.scratch + 4 * H, 6 * H);
         GemmBuilder::seg(p1, c.vbar, D, nullptr, w.W1_is_weight + voff, in1, D);
         GemmProb& p2 = g.prob(B, H, c.scratch + 5 * H, 6 * H);
         GemmBuilder::seg(p2, c.vbar, D, nullptr, w.W1_ig_weight + voff, in1, D);
-        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const int ns = g.finish(h);
         const long long stride = (long long)B * 6 * H;
-        for (int i = 0; i < 3; ++i) g.a.p[i].split_stride = stride;
+        for (int i = 0; i < 3; ++i) g.a.p[i].slab_stride = stride;
         if (g.launch(s, h)) return fail("vproj gemm launch failed");
         const long long n = (long long)B * 6 * H;
         hipLaunchKernelGGL(k_vproj_finish, dim3(cdiv(n, 256)), dim3(256), 0, s, c.scratch, ns, stride, B, H,
@@ -335,24 +317,26 @@ extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R
     }
     if (d.img_second_lstm) {
         const int in2 = H + 2 * D;
-        GemmBuilder g(h->gemm_tile);
+        GemmBuilder g;
         GemmProb& p0 = g.prob(B, 4 * H, c.scratch, 4 * H);
         GemmBuilder::seg(p0, c.vbar, D, nullptr, w.lstm2_weight_ih + H + D, in2, D);
-        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const int ns = g.finish(h);
         const long long stride = (long long)B * 4 * H;
-        g.a.p[0].split_stride = stride;
+        g.a.p[0].slab_stride = stride;
         if (g.launch(s, h)) return fail("vproj2 gemm launch failed");
         hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.vproj2);
         LAUNCHCHK();
     }
-    // att_va over every region row of every slot: (B*L*R, D) x (A, D)^T -> P, written in place (no split)
+    // att_va over every region row of every slot: (B*L*R, D) x (A, D)^T -> P
     {
-        GemmBuilder g(rows >= 512 ? 128 : h->gemm_tile);
-        GemmProb& p0 = g.prob((int)rows, A, c.P, A);
+        GemmBuilder g;
+        GemmProb& p0 = g.prob((int)rows, A, c.scratch, A);
         GemmBuilder::seg(p0, regions, D, nullptr, w.att_va_weight, D, D);
-        g.finish(1, 0);
-        g.a.p[0].split_stride = 0;
+        const int ns = g.finish(h);
+        const long long stride = rows * A;
+        g.a.p[0].slab_stride = stride;
         if (g.launch(s, h)) return fail("att_va gemm launch failed");
+        hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.P);
         LAUNCHCHK();
     }
     h->prepared = true;
@@ -391,7 +375,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
 
     // ---- S1
     {
-        GemmBuilder g(h->gemm_tile);
+        GemmBuilder g;
         const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
         const float* Whh[3] = {w.lstm1_weight_hh, w.W1_hs_weight, nullptr};
         const int Nn[3] = {4 * H, H, H};
@@ -402,16 +386,16 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
             GemmBuilder::seg(p, w.embed_weight, E, io.word_prev, Wih[i] + xoff, in1, E);
             if (Whh[i] && io.t > 0) GemmBuilder::seg(p, h1o, H, io.parent, Whh[i], H, H);
         }
-        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const int ns = g.finish(h);
         const long long stride = (long long)M * 6 * H;
-        for (int i = 0; i < 3; ++i) g.a.p[i].split_stride = stride;
+        for (int i = 0; i < 3; ++i) g.a.p[i].slab_stride = stride;
         if (g.launch(s, h)) return fail("S1 gemm launch failed");
         hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj, io.rpi,
                            io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre);
     }
     // ---- S2
     {
-        GemmBuilder g(h->gemm_tile);
+        GemmBuilder g;
         float* c2a = c.scratch;
         float* c2b_base;
         GemmProb& p0 = g.prob(M, H, c2a, H + A);
@@ -422,12 +406,12 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         GemmBuilder::seg(p2, c.s_t, H, nullptr, w.s_fc_weight, H, H);
         GemmProb& p3 = g.prob(M, A, nullptr, D + A);
         GemmBuilder::seg(p3, c.s_t, H, nullptr, w.att_sa_weight, H, H);
-        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const int ns = g.finish(h);
         const long long stride_a = (long long)M * (H + A), stride_b = (long long)M * (D + A);
         c2b_base = c2a + stride_a * ns;
-        g.a.p[0].split_stride = g.a.p[1].split_stride = stride_a;
+        g.a.p[0].slab_stride = g.a.p[1].slab_stride = stride_a;
         g.a.p[2].C = c2b_base; g.a.p[3].C = c2b_base + D;
-        g.a.p[2].split_stride = g.a.p[3].split_stride = stride_b;
+        g.a.p[2].slab_stride = g.a.p[3].slab_stride = stride_b;
         if (g.launch(s, h)) return fail("S2 gemm launch failed");
         const long long n = (long long)M * (H + A + D + A);
         hipLaunchKernelGGL(k_gate2, dim3(cdiv(n, 256)), dim3(256), 0, s, c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n,
@@ -441,18 +425,18 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     }
     // ---- S5
     {
-        GemmBuilder g(h->gemm_tile);
+        GemmBuilder g;
         GemmProb& p0 = g.prob(M, 4 * H, c.scratch, 4 * H);
         GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H);
         GemmBuilder::seg(p0, c.att, D, nullptr, w.lstm2_weight_ih + H, in2, D);
         if (io.t > 0) GemmBuilder::seg(p0, h2o, H, io.parent, w.lstm2_weight_hh, H, H);
         GemmProb& p1 = g.prob(M, A, nullptr, A);
         GemmBuilder::seg(p1, c.g_t, H, nullptr, w.att_ga_weight, H, H);
-        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const int ns = g.finish(h);
         const long long stride = (long long)M * 4 * H, stride_g = (long long)M * A;
         float* ga = c.scratch + stride * ns;
-        g.a.p[0].split_stride = stride;
-        g.a.p[1].C = ga; g.a.p[1].split_stride = stride_g;
+        g.a.p[0].slab_stride = stride;
+        g.a.p[1].C = ga; g.a.p[1].slab_stride = stride_g;
         if (g.launch(s, h)) return fail("S5 gemm launch failed");
         hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
                            w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n);
@@ -461,12 +445,12 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     }
     // ---- S6
     {
-        GemmBuilder g(h->gemm_tile);
+        GemmBuilder g;
         GemmProb& p0 = g.prob(M, V, c.scratch, V);
         GemmBuilder::seg(p0, h2n, H, nullptr, w.out_fc_weight, H, H);
-        const int ns = g.finish(h->target_units, c.scratch_floats);
+        const int ns = g.finish(h);
         const long long stride = (long long)M * V;
-        g.a.p[0].split_stride = stride;
+        g.a.p[0].slab_stride = stride;
         if (g.launch(s, h)) return fail("S6 gemm launch failed");
 #define VOCAB_ARGS c.scratch, ns, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
                    io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs
