@@ -127,7 +127,7 @@ def test_live_against_reference(tmp_path, monkeypatch):
     # run in a subprocess: the reference's package is also called `models`
     code = r'''
 import sys, json, os
-sys.path.insert(0, "/root/reference"); sys.path.insert(0, %r); sys.path.insert(0, %r)
+sys.path.insert(0, "/root/reference"); sys.path.append(%r); sys.path.insert(0, %r)   # the reference's `models` must win
 import torch, numpy as np
 from vsrcap import synth
 import vsr_oracle as vo

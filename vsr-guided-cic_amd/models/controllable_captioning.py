@@ -91,8 +91,9 @@ class ControllableCaptioningModel(CaptioningModel):
                                     h2_first_lstm=int(self.h2_first_lstm), img_second_lstm=int(self.img_second_lstm)))
             self._verb_dev = None
         params = {k: v.data for k, v in self.named_parameters()}
-        if next(iter(params.values())).device != device:
-            raise RuntimeError("model parameters are on %s but the inputs are on %s" % (next(iter(params.values())).device, device))
+        pdev = next(iter(params.values())).device
+        if pdev.type != 'cuda' or (device.index is not None and pdev.index != device.index):
+            raise RuntimeError("model parameters are on %s but the inputs are on %s" % (pdev, device))
         self._eng.bind(params)
         return self._eng
 
