@@ -128,6 +128,24 @@ int vsr_step(vsr_handle* h, int32_t t, int32_t rows_per_image, const int64_t* pr
              float* h1_out, float* c1_out, float* h2_out, float* c2_out, int64_t* slot_out,
              const float* verbs, int32_t gt, float* logp_words, float* logp_gates, void* stream);
 
+/* ---- training: forward with saved activations + hand-written BPTT backward ---------------------------
+ * replaces autograd through CaptioningModel.forward (XE, coco_scripts/train.py:103-113) and through
+ * sample_rl's log-probs (SCST, train.py:151-178).  vsr_prepare(beam = 1) must have been called with the region
+ * tensor the steps read: seqs[1] (B,T,R,D) for XE (slots = NULL: step t reads slot t) or statics[1] (B,L,R,D)
+ * plus the slot trace (B,T) for a replayed sample.
+ *   word_in (B,T) int64: word fed at step t (XE: captions; SCST: [bos, sample[:, :-1]])
+ *   logp_words (B,T,V), logp_gates (B,T,2): outputs; they and the training workspace must stay untouched until
+ *   vsr_train_backward, which overwrites the 28 tensors of *grads (same layout / field order as vsr_weights)
+ *   with dLoss/dW given dLoss/dlogp_words and dLoss/dlogp_gates. */
+size_t vsr_train_workspace_bytes(const vsr_handle* h, int32_t B, int32_t T);
+int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const int64_t* slots, int32_t T, float* logp_words,
+                      float* logp_gates, void* train_workspace, size_t train_workspace_bytes, void* stream);
+int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, const float* grad_logp_gates, const vsr_weights* grads,
+                       void* stream);
+
+/* test hook: copy an internal buffer of the saved training pass ("dpre1", "dpre2", "dh2_voc", "gates1", ...) */
+int vsr_debug_copy(vsr_handle* h, const char* name, float* dst, size_t n_floats, void* stream);
+
 /* ---- measurement (bench.py roofline leg) ------------------------------------------------------------ */
 /* Between begin and end every fp32-MFMA GEMM launch is bracketed by a pair of pre-created HIP events on the
  * caller's stream.  end() synchronises the stream and returns the summed launch durations, the number of

@@ -143,7 +143,8 @@ __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long str
 __global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__ c2b, int nsplit, long long stride_a,
                         long long stride_b, const float* __restrict__ gpre, const float* __restrict__ c1n,
                         const float* __restrict__ b_sfc, int M, int H, int A, int D, float* __restrict__ g_t,
-                        float* __restrict__ hA, float* __restrict__ sent, float* __restrict__ sa) {
+                        float* __restrict__ hA, float* __restrict__ sent, float* __restrict__ sa,
+                        float* __restrict__ gates6 /* optional (M,6H): column block 5 receives the shift gate */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int W = H + A + D + A;
     if (i >= (long long)M * W) return;
@@ -153,7 +154,9 @@ __global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__
         for (int k = 0; k < nsplit; ++k) s += c2a[k * stride_a + (long long)row * (H + A) + c];
         if (c < H) {
             const long long o = (long long)row * H + c;
-            g_t[o] = sigmoidf_(gpre[o] + s) * tanhf(c1n[o]);
+            const float gg = sigmoidf_(gpre[o] + s);
+            g_t[o] = gg * tanhf(c1n[o]);
+            if (gates6) gates6[(long long)row * 6 * H + 5LL * H + c] = gg;
         } else {
             hA[(long long)row * A + (c - H)] = s;
         }

@@ -1,0 +1,528 @@
+// Training path of libvsrcap.so: teacher-forced (or sample-replayed) forward that saves activations, and the
+// hand-written BPTT backward.  Included at the end of vsrcap.hip.
+//
+// Reference: coco_scripts/train.py:103-113 (XE: model(...) -> NLL losses -> loss.backward()) and :151-178 (SCST:
+// sample_rl log-probs -> loss.backward()); the graph autograd differentiates there is step :117-190 unrolled T times.
+//
+// Backward structure (B rows, T steps, rows of the "all-steps" matrices ordered (t, b)):
+//   phase 0  dlogits for all steps (log_softmax backward) and dh2_vocab = dlogits . W_out        one big GEMM
+//   phase A  t = T-1 .. 0: pointwise backward kernels + 3 grouped GEMMs per step against TRANSPOSED weights
+//            (data gradients only): dpre2_t, dpre1_t, d[hg|hA]_t, d[sent|sa]_t, dga_t, dP rows, state carries
+//   phase B  all weight gradients as big GEMMs with the reduction over the T*B rows:
+//            dW[n][k] = sum_rows dY^T[n][row] * X^T[k][row]   (both operands transposed once per call)
+// so every matrix product of the backward pass runs on the same stream-K fp32-MFMA kernel as the forward pass.
+
+struct TrainCtx {
+    bool valid = false;
+    int B = 0, T = 0, TB = 0, TBp = 0, Bp = 0, RLp = 0;
+    const float* logp_w = nullptr;     // caller's (B,T,V) output of the forward, needed by the backward
+    const float* logp_g = nullptr;     // (B,T,2)
+    float *h1s, *c1s, *h2s, *c2s;      // (T+1, B, H): slot 0 = zeros
+    float *gates1, *gates2, *s_ts, *g_ts, *hAs, *sas, *gas, *sents, *atts, *alphas, *x_all;
+    int *word32, *slot32;
+    float *dlogits, *dh2_voc, *dpre1, *dpre2, *dhA_all, *dsent_all, *dsa_all, *dga_all, *dwa_rows, *dws_rows, *dwg_rows, *dP;
+    float *datt, *dg_t, *dtc, *ds_t, *dh_tot, *dzsum, *dh1_c, *dh2_c, *dc1_c[2], *dc2_c[2], *dpre1sum, *dpre2sum, *dx_all;
+    float *wT_ih1, *wT_is, *wT_ig, *wT_hh1, *wT_hs, *wT_ih2, *wT_hh2, *wT_hg, *wT_ha, *wT_sfc, *wT_sa, *wT_ga, *wT_out;
+    float *tX_h2prev, *tX_x, *tX_h1prev, *tX_h1, *tX_att, *tX_st, *tX_gt, *tX_h2, *tX_vbar, *tX_reg;
+    float *tY_dpre1, *tY_dpre2, *tY_dlogits, *tY_dhA, *tY_dsent, *tY_dsa, *tY_dga, *tY_dpre1sum, *tY_dpre2sum, *tY_dP;
+    float* scratch;
+    size_t scratch_floats = 0;
+    char* tpad_begin = nullptr;        // transposed-activation region (zeroed when its rows are padded)
+    size_t tpad_bytes = 0;
+};
+
+static TrainCtx g_tc_dummy;
+
+static inline size_t up4(size_t x) { return (x + 3) & ~size_t(3); }
+
+static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
+    const vsr_dims& d = h->d;
+    const Ctx& c = h->c;
+    const size_t B = t.B, T = t.T, H = d.rnn_size, A = d.att_size, D = d.det_feat_size, E = d.input_encoding_size, V = d.vocab_size;
+    const size_t in1 = (d.h2_first_lstm ? H : 0) + D + E, in2 = H + D + (d.img_second_lstm ? D : 0);
+    const size_t TB = T * B, TBp = up4(TB), Bp = up4(B), RL = (size_t)c.B * c.L * c.R, RLp = up4(RL), R1 = c.R + 1;
+    t.TB = (int)TB; t.TBp = (int)TBp; t.Bp = (int)Bp; t.RLp = (int)RLp;
+    Bump b{base};
+    t.h1s = b.take<float>((T + 1) * B * H); t.c1s = b.take<float>((T + 1) * B * H);
+    t.h2s = b.take<float>((T + 1) * B * H); t.c2s = b.take<float>((T + 1) * B * H);
+    t.gates1 = b.take<float>(TB * 6 * H); t.gates2 = b.take<float>(TB * 4 * H);
+    t.s_ts = b.take<float>(TB * H); t.g_ts = b.take<float>(TB * H);
+    t.hAs = b.take<float>(TB * A); t.sas = b.take<float>(TB * A); t.gas = b.take<float>(TB * A);
+    t.sents = b.take<float>(TB * D); t.atts = b.take<float>(TB * D); t.alphas = b.take<float>(TB * R1);
+    t.x_all = b.take<float>(TB * E);
+    t.word32 = b.take<int>(TB); t.slot32 = b.take<int>(TB);
+    t.dlogits = b.take<float>(TB * up4(V)); t.dh2_voc = b.take<float>(TB * H);
+    t.dpre1 = b.take<float>(TB * 6 * H); t.dpre2 = b.take<float>(TB * 4 * H);
+    t.dhA_all = b.take<float>(TB * A); t.dsent_all = b.take<float>(TB * D); t.dsa_all = b.take<float>(TB * A); t.dga_all = b.take<float>(TB * A);
+    t.dwa_rows = b.take<float>(TB * A); t.dws_rows = b.take<float>(TB * A); t.dwg_rows = b.take<float>(TB * A);
+    t.dP = b.take<float>(RL * A);
+    t.datt = b.take<float>(B * D); t.dg_t = b.take<float>(B * H); t.dtc = b.take<float>(B * H); t.ds_t = b.take<float>(B * H);
+    t.dh_tot = b.take<float>(B * H); t.dzsum = b.take<float>(B);
+    t.dh1_c = b.take<float>(B * H); t.dh2_c = b.take<float>(B * H);
+    for (int i = 0; i < 2; ++i) { t.dc1_c[i] = b.take<float>(B * H); t.dc2_c[i] = b.take<float>(B * H); }
+    t.dpre1sum = b.take<float>(B * 6 * H); t.dpre2sum = b.take<float>(B * 4 * H); t.dx_all = b.take<float>(TB * E);
+    t.wT_ih1 = b.take<float>(in1 * 4 * H); t.wT_is = b.take<float>(in1 * H); t.wT_ig = b.take<float>(in1 * H);
+    t.wT_hh1 = b.take<float>(H * 4 * H); t.wT_hs = b.take<float>(H * H);
+    t.wT_ih2 = b.take<float>(in2 * 4 * H); t.wT_hh2 = b.take<float>(H * 4 * H);
+    t.wT_hg = b.take<float>(H * H); t.wT_ha = b.take<float>(H * A); t.wT_sfc = b.take<float>(H * D);
+    t.wT_sa = b.take<float>(H * A); t.wT_ga = b.take<float>(H * A); t.wT_out = b.take<float>(H * up4(V));
+    b.off = (b.off + 255) & ~size_t(255);
+    const size_t tp0 = b.off;
+    t.tX_h2prev = b.take<float>(H * TBp); t.tX_x = b.take<float>(E * TBp); t.tX_h1prev = b.take<float>(H * TBp);
+    t.tX_h1 = b.take<float>(H * TBp); t.tX_att = b.take<float>(D * TBp); t.tX_st = b.take<float>(H * TBp);
+    t.tX_gt = b.take<float>(H * TBp); t.tX_h2 = b.take<float>(H * TBp); t.tX_vbar = b.take<float>(D * Bp);
+    t.tX_reg = b.take<float>(D * RLp);
+    t.tY_dpre1 = b.take<float>(6 * H * TBp); t.tY_dpre2 = b.take<float>(4 * H * TBp); t.tY_dlogits = b.take<float>(V * TBp);
+    t.tY_dhA = b.take<float>(A * TBp); t.tY_dsent = b.take<float>(D * TBp); t.tY_dsa = b.take<float>(A * TBp); t.tY_dga = b.take<float>(A * TBp);
+    t.tY_dpre1sum = b.take<float>(6 * H * Bp); t.tY_dpre2sum = b.take<float>(4 * H * Bp); t.tY_dP = b.take<float>(A * RLp);
+    t.tpad_begin = base ? base + tp0 : nullptr;
+    t.tpad_bytes = b.off - tp0;
+    // GEMM slab scratch: 8 slabs of the largest product of the training path
+    size_t big = std::max({4 * H * in1, V * H, 4 * H * in2, A * D, TB * H, TB * E, D * H, B * (in2 + 2 * H), H * in1});
+    t.scratch_floats = big * 8;
+    t.scratch = b.take<float>(t.scratch_floats);
+    return (b.off + 255) & ~size_t(255);
+}
+
+struct SegSpec { const float* A; int lda; const float* W; int ldw; int K; };
+
+// one problem, several K segments -> dst window (ldd), through the slab scratch
+static int gemm_to(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, const SegSpec* segs, int nseg, float* dst, long long ldd) {
+    GemmBuilder g;
+    GemmProb& p = g.prob(M, N, t.scratch, N);
+    for (int i = 0; i < nseg; ++i) GemmBuilder::seg(p, segs[i].A, segs[i].lda, nullptr, segs[i].W, segs[i].ldw, segs[i].K);
+    const int ns = g.finish(h);
+    const long long stride = (long long)M * N;
+    if ((size_t)stride * ns > t.scratch_floats) return fail("training scratch too small (%lld x %d)", stride, ns);
+    g.a.p[0].slab_stride = stride;
+    if (g.launch(s, h)) return fail("training gemm launch failed");
+    hipLaunchKernelGGL(k_slab_reduce_2d, dim3(cdiv(stride, 256)), dim3(256), 0, s, t.scratch, ns, stride, M, N, dst, ldd);
+    return 0;
+}
+static int gemm_to1(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, int K, const float* A, int lda, const float* W, int ldw,
+                    float* dst, long long ldd) {
+    SegSpec sg{A, lda, W, ldw, K};
+    return gemm_to(h, t, s, M, N, &sg, 1, dst, ldd);
+}
+static void transpose(hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out) {
+    hipLaunchKernelGGL(k_transpose, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, in, ld_in, R, C, out, ld_out);
+}
+
+extern "C" size_t vsr_train_workspace_bytes(const vsr_handle* h, int32_t B, int32_t T) {
+    if (!h || !h->prepared || B != h->c.B || T <= 0) return 0;
+    TrainCtx t;
+    t.B = B; t.T = T;
+    return carve_train(h, t, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------- forward with saves
+extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const int64_t* slots, int32_t T, float* logp_words,
+                                 float* logp_gates, void* train_ws, size_t train_ws_bytes, void* stream) {
+    if (check_ready(h, "vsr_train_forward")) return 1;
+    if (!word_in || !logp_words || !logp_gates || !train_ws) return fail("vsr_train_forward: null tensor");
+    Ctx& c = h->c;
+    if (c.beam != 1 && c.Mmax != c.B) return fail("vsr_train_forward: prepare() must be called with beam = 1");
+    if (!slots && T != c.L) return fail("vsr_train_forward: without a slot trace the regions must have one slot per step (T %d, L %d)", T, c.L);
+    hipStream_t s = (hipStream_t)stream;
+    const vsr_dims& d = h->d;
+    const vsr_weights& w = h->w;
+    const int B = c.B, H = d.rnn_size, A = d.att_size, D = d.det_feat_size, E = d.input_encoding_size, V = d.vocab_size;
+    const int in1 = (d.h2_first_lstm ? H : 0) + D + E, xoff = (d.h2_first_lstm ? H : 0) + D, in2 = H + D + (d.img_second_lstm ? D : 0);
+    TrainCtx& t = *h->tc;
+    t.valid = false;
+    t.B = B; t.T = T;
+    const size_t need = carve_train(h, t, reinterpret_cast<char*>(train_ws));
+    if (need > train_ws_bytes) return fail("vsr_train_forward: training workspace too small (%zu < %zu)", train_ws_bytes, need);
+    const int TB = T * B;
+    const size_t BH = (size_t)B * H;
+    HIPCHK(hipMemsetAsync(t.h1s, 0, BH * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(t.c1s, 0, BH * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(t.h2s, 0, BH * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(t.c2s, 0, BH * sizeof(float), s));
+    for (int tt = 0; tt < T; ++tt) {
+        hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, word_in + tt, (long long)T, t.word32 + (size_t)tt * B, B);
+        if (slots) hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, slots + tt, (long long)T, t.slot32 + (size_t)tt * B, B);
+        else hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, t.slot32 + (size_t)tt * B, tt, B);
+    }
+    hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((long long)TB * E, 256)), dim3(256), 0, s, w.embed_weight, t.word32, TB, E, t.x_all);
+    LAUNCHCHK();
+
+    for (int tt = 0; tt < T; ++tt) {
+        const float *h1o = t.h1s + (size_t)tt * BH, *c1o = t.c1s + (size_t)tt * BH, *h2o = t.h2s + (size_t)tt * BH, *c2o = t.c2s + (size_t)tt * BH;
+        float *h1n = t.h1s + (size_t)(tt + 1) * BH, *c1n = t.c1s + (size_t)(tt + 1) * BH, *h2n = t.h2s + (size_t)(tt + 1) * BH, *c2n = t.c2s + (size_t)(tt + 1) * BH;
+        float* g1 = t.gates1 + (size_t)tt * B * 6 * H;
+        float* g2 = t.gates2 + (size_t)tt * B * 4 * H;
+        float *s_t = t.s_ts + (size_t)tt * BH, *g_t = t.g_ts + (size_t)tt * BH;
+        float *hA = t.hAs + (size_t)tt * B * A, *sa = t.sas + (size_t)tt * B * A, *ga = t.gas + (size_t)tt * B * A;
+        float *sent = t.sents + (size_t)tt * B * D, *att = t.atts + (size_t)tt * B * D, *alpha = t.alphas + (size_t)tt * B * (c.R + 1);
+        const float* x = t.x_all + (size_t)tt * B * E;
+        const int* slot = t.slot32 + (size_t)tt * B;
+        {   // S1
+            GemmBuilder g;
+            const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
+            const float* Whh[3] = {w.lstm1_weight_hh, w.W1_hs_weight, nullptr};
+            const int Nn[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
+            for (int i = 0; i < 3; ++i) {
+                GemmProb& p = g.prob(B, Nn[i], c.scratch + off[i], 6 * H);
+                if (d.h2_first_lstm && tt > 0) GemmBuilder::seg(p, h2o, H, nullptr, Wih[i], in1, H);
+                GemmBuilder::seg(p, x, E, nullptr, Wih[i] + xoff, in1, E);
+                if (Whh[i] && tt > 0) GemmBuilder::seg(p, h1o, H, nullptr, Whh[i], H, H);
+            }
+            const int ns = g.finish(h);
+            const long long stride = (long long)B * 6 * H;
+            for (int i = 0; i < 3; ++i) g.a.p[i].slab_stride = stride;
+            if (g.launch(s, h)) return fail("train S1 gemm launch failed");
+            hipLaunchKernelGGL(k_lstm1_train, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj, c1o, B, H,
+                               h1n, c1n, s_t, c.gpre, g1);
+        }
+        {   // S2
+            GemmBuilder g;
+            GemmProb& p0 = g.prob(B, H, c.scratch, H + A);
+            GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H);
+            GemmProb& p1 = g.prob(B, A, c.scratch + H, H + A);
+            GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H);
+            GemmProb& p2 = g.prob(B, D, nullptr, D + A);
+            GemmBuilder::seg(p2, s_t, H, nullptr, w.s_fc_weight, H, H);
+            GemmProb& p3 = g.prob(B, A, nullptr, D + A);
+            GemmBuilder::seg(p3, s_t, H, nullptr, w.att_sa_weight, H, H);
+            const int ns = g.finish(h);
+            const long long stride_a = (long long)B * (H + A), stride_b = (long long)B * (D + A);
+            float* c2b = c.scratch + stride_a * ns;
+            g.a.p[0].slab_stride = g.a.p[1].slab_stride = stride_a;
+            g.a.p[2].C = c2b; g.a.p[3].C = c2b + D;
+            g.a.p[2].slab_stride = g.a.p[3].slab_stride = stride_b;
+            if (g.launch(s, h)) return fail("train S2 gemm launch failed");
+            const long long n = (long long)B * (H + A + D + A);
+            hipLaunchKernelGGL(k_gate2, dim3(cdiv(n, 256)), dim3(256), 0, s, c.scratch, c2b, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias,
+                               B, H, A, D, g_t, hA, sent, sa, g1);
+        }
+        {
+            const size_t smem = (size_t)(A + c.R + 1 + 8) * sizeof(float);
+            hipLaunchKernelGGL(k_attend, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, hA, sa, sent, c.P, c.regions, c.rmask, slot, 0, 1, B, c.L,
+                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
+        }
+        {   // S5
+            GemmBuilder g;
+            GemmProb& p0 = g.prob(B, 4 * H, c.scratch, 4 * H);
+            GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H);
+            GemmBuilder::seg(p0, att, D, nullptr, w.lstm2_weight_ih + H, in2, D);
+            if (tt > 0) GemmBuilder::seg(p0, h2o, H, nullptr, w.lstm2_weight_hh, H, H);
+            GemmProb& p1 = g.prob(B, A, nullptr, A);
+            GemmBuilder::seg(p1, g_t, H, nullptr, w.att_ga_weight, H, H);
+            const int ns = g.finish(h);
+            const long long stride = (long long)B * 4 * H, stride_g = (long long)B * A;
+            float* gas = c.scratch + stride * ns;
+            g.a.p[0].slab_stride = stride;
+            g.a.p[1].C = gas; g.a.p[1].slab_stride = stride_g;
+            if (g.launch(s, h)) return fail("train S5 gemm launch failed");
+            hipLaunchKernelGGL(k_lstm2_train, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
+                               w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, c2o, B, H, h2n, c2n, g2);
+            hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride_g, 256)), dim3(256), 0, s, gas, ns, stride_g, stride_g, ga);
+            hipLaunchKernelGGL(k_gatelogit, dim3(cdiv(B, 4)), dim3(256), 0, s, ga, 1, stride_g, hA, w.att_g_weight, c.zsum, (const float*)nullptr,
+                               slot, 1, c.L, B, A, logp_gates + (size_t)tt * 2, (long long)T * 2);
+        }
+        {   // S6
+            GemmBuilder g;
+            GemmProb& p0 = g.prob(B, V, c.scratch, V);
+            GemmBuilder::seg(p0, h2n, H, nullptr, w.out_fc_weight, H, H);
+            const int ns = g.finish(h);
+            const long long stride = (long long)B * V;
+            g.a.p[0].slab_stride = stride;
+            if (g.launch(s, h)) return fail("train S6 gemm launch failed");
+            hipLaunchKernelGGL((k_vocab<1>), dim3(B), dim3(256), 0, s, c.scratch, ns, stride, w.out_fc_bias, B, V, (int)VM_FULL, c.top_v, c.top_i,
+                               logp_words + (size_t)tt * V, (long long)T * V, (const int*)nullptr, (uint64_t)0, (uint32_t)tt,
+                               (const float*)nullptr, slot, 1, c.L, 0, h->vt_ptr, h->vt_ids, h->n_verbs);
+        }
+        LAUNCHCHK();
+    }
+    t.logp_w = logp_words;
+    t.logp_g = logp_gates;
+    t.valid = true;
+    return 0;
+}
+
+// dlogits in (t, b) row order from the (B, T, V) tensors
+__global__ __launch_bounds__(256) void k_dlogits_tb(const float* __restrict__ logp, const float* __restrict__ dlogp, int B, int T, int V,
+                                                    int Vp, float* __restrict__ dlogits) {
+    __shared__ float red[4];
+    const int tt = blockIdx.x / B, b = blockIdx.x % B;
+    const long long src = ((long long)b * T + tt) * V, dst = (long long)blockIdx.x * Vp;
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int v = tid; v < V; v += 256) s += dlogp[src + v];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int v = tid; v < Vp; v += 256) dlogits[dst + v] = v < V ? dlogp[src + v] - expf(logp[src + v]) * tot : 0.f;
+}
+
+__global__ void k_sum_over_t(const float* __restrict__ X, int T, long long per_t, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_t) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += X[t * per_t + i];
+    out[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, const float* grad_logp_gates, const vsr_weights* grads,
+                                  void* stream) {
+    if (check_ready(h, "vsr_train_backward")) return 1;
+    TrainCtx& t = *h->tc;
+    if (!t.valid) return fail("vsr_train_backward: no saved forward (call vsr_train_forward first)");
+    if (!grad_logp_words || !grad_logp_gates || !grads) return fail("vsr_train_backward: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const vsr_dims& d = h->d;
+    const vsr_weights& w = h->w;
+    Ctx& c = h->c;
+    const int B = t.B, T = t.T, TB = t.TB, TBp = t.TBp, Bp = t.Bp, RLp = t.RLp;
+    const int H = d.rnn_size, A = d.att_size, D = d.det_feat_size, E = d.input_encoding_size, V = d.vocab_size;
+    const int in1 = (d.h2_first_lstm ? H : 0) + D + E, voff = d.h2_first_lstm ? H : 0, xoff = voff + D, in2 = H + D + (d.img_second_lstm ? D : 0);
+    const int RL = c.B * c.L * c.R, R1 = c.R + 1;
+    const size_t BH = (size_t)B * H;
+    float* const* G = reinterpret_cast<float* const*>(grads);     // same field order as vsr_weights
+    enum { g_embed, g_Wis, g_bis, g_Whs, g_bhs, g_Wva, g_Wha, g_wa, g_Wsa, g_ws, g_Wih1, g_Whh1, g_bih1, g_bhh1, g_Wih2, g_Whh2, g_bih2,
+           g_bhh2, g_Wout, g_bout, g_Wsfc, g_bsfc, g_Wig, g_big, g_Whg, g_bhg, g_Wga, g_wg };
+    for (int i = 0; i < 28; ++i)
+        if (!G[i]) return fail("vsr_train_backward: gradient pointer %d is null", i);
+
+    // ---- transposed weights (the optimizer may have changed them since the last call)
+    transpose(s, w.lstm1_weight_ih, in1, 4 * H, in1, t.wT_ih1, 4 * H);
+    transpose(s, w.W1_is_weight, in1, H, in1, t.wT_is, H);
+    transpose(s, w.W1_ig_weight, in1, H, in1, t.wT_ig, H);
+    transpose(s, w.lstm1_weight_hh, H, 4 * H, H, t.wT_hh1, 4 * H);
+    transpose(s, w.W1_hs_weight, H, H, H, t.wT_hs, H);
+    transpose(s, w.lstm2_weight_ih, in2, 4 * H, in2, t.wT_ih2, 4 * H);
+    transpose(s, w.lstm2_weight_hh, H, 4 * H, H, t.wT_hh2, 4 * H);
+    transpose(s, w.W1_hg_weight, H, H, H, t.wT_hg, H);
+    transpose(s, w.att_ha_weight, H, A, H, t.wT_ha, A);
+    transpose(s, w.s_fc_weight, H, D, H, t.wT_sfc, D);
+    transpose(s, w.att_sa_weight, H, A, H, t.wT_sa, A);
+    transpose(s, w.att_ga_weight, H, A, H, t.wT_ga, A);
+    const int Vp = (int)up4(V);        // K of the dh2_vocab GEMM must be a multiple of 4: zero-padded columns
+    if (Vp != V) HIPCHK(hipMemsetAsync(t.wT_out, 0, (size_t)H * Vp * sizeof(float), s));
+    transpose(s, w.out_fc_weight, H, V, H, t.wT_out, Vp);
+    HIPCHK(hipMemsetAsync(t.dP, 0, (size_t)RL * A * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(t.dh1_c, 0, BH * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(t.dh2_c, 0, BH * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(t.dc1_c[0], 0, BH * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(t.dc2_c[0], 0, BH * sizeof(float), s));
+    if (TBp != TB || Bp != B || RLp != RL) HIPCHK(hipMemsetAsync(t.tpad_begin, 0, t.tpad_bytes, s));
+
+    // ---- phase 0: dlogits (t,b) and the vocabulary part of dh2 for every step
+    hipLaunchKernelGGL(k_dlogits_tb, dim3(TB), dim3(256), 0, s, t.logp_w, grad_logp_words, B, T, V, Vp, t.dlogits);
+    if (gemm_to1(h, t, s, TB, H, Vp, t.dlogits, Vp, t.wT_out, Vp, t.dh2_voc, H)) return 1;
+    LAUNCHCHK();
+
+    // ---- phase A: reverse time
+    int cb = 0;
+    for (int tt = T - 1; tt >= 0; --tt, cb ^= 1) {
+        const float *c1 = t.c1s + (size_t)(tt + 1) * BH, *c1p = t.c1s + (size_t)tt * BH;
+        const float *c2 = t.c2s + (size_t)(tt + 1) * BH, *c2p = t.c2s + (size_t)tt * BH;
+        const float* g1 = t.gates1 + (size_t)tt * B * 6 * H;
+        const float* g2 = t.gates2 + (size_t)tt * B * 4 * H;
+        const float *hA = t.hAs + (size_t)tt * B * A, *sa = t.sas + (size_t)tt * B * A, *ga = t.gas + (size_t)tt * B * A;
+        const float *sent = t.sents + (size_t)tt * B * D, *alpha = t.alphas + (size_t)tt * B * R1;
+        const int* slot = t.slot32 + (size_t)tt * B;
+        float* dpre1 = t.dpre1 + (size_t)tt * B * 6 * H;
+        float* dpre2 = t.dpre2 + (size_t)tt * B * 4 * H;
+        float *dhA = t.dhA_all + (size_t)tt * B * A, *dsent = t.dsent_all + (size_t)tt * B * D, *dsa = t.dsa_all + (size_t)tt * B * A;
+        float* dga = t.dga_all + (size_t)tt * B * A;
+        float *dwa = t.dwa_rows + (size_t)tt * B * A, *dws = t.dws_rows + (size_t)tt * B * A, *dwg = t.dwg_rows + (size_t)tt * B * A;
+
+        // gate log-probs -> dga, dhA (first writer), dzsum
+        hipLaunchKernelGGL(k_gatelogit_bwd, dim3(cdiv(B, 4)), dim3(256), 0, s, t.logp_g + (size_t)tt * 2, grad_logp_gates + (size_t)tt * 2,
+                           (long long)T * 2, ga, hA, w.att_g_weight, B, A, dga, dhA, t.dzsum, dwg);
+        // LSTM2
+        hipLaunchKernelGGL(k_add3, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.dh2_voc + (size_t)tt * BH, t.dh2_c, (const float*)nullptr,
+                           (long long)BH, t.dh_tot);
+        hipLaunchKernelGGL(k_lstm_bwd, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.dh_tot, t.dc2_c[cb], (const float*)nullptr, g2,
+                           (long long)4 * H, c2, tt > 0 ? c2p : (const float*)nullptr, B, H, dpre2, (long long)4 * H, t.dc2_c[cb ^ 1]);
+        // grouped GEMM 1: dpre2 -> [dh1_a | datt (| dvbar)] , dh2 carry (hh part);  dga -> dg_t
+        int ns1;
+        long long st0, st1, st2;
+        float *C0, *C1, *C2;
+        {
+            GemmBuilder g;
+            GemmProb& p0 = g.prob(B, H + D, nullptr, H + D);
+            GemmBuilder::seg(p0, dpre2, 4 * H, nullptr, t.wT_ih2, 4 * H, 4 * H);
+            GemmProb& p1 = g.prob(B, H, nullptr, H);
+            GemmBuilder::seg(p1, dpre2, 4 * H, nullptr, t.wT_hh2, 4 * H, 4 * H);
+            GemmProb& p2 = g.prob(B, H, nullptr, H);
+            GemmBuilder::seg(p2, dga, A, nullptr, t.wT_ga, A, A);
+            ns1 = g.finish(h);
+            st0 = (long long)B * (H + D); st1 = (long long)B * H; st2 = (long long)B * H;
+            C0 = t.scratch; C1 = C0 + st0 * ns1; C2 = C1 + st1 * ns1;
+            g.a.p[0].C = C0; g.a.p[0].slab_stride = st0;
+            g.a.p[1].C = C1; g.a.p[1].slab_stride = st1;
+            g.a.p[2].C = C2; g.a.p[2].slab_stride = st2;
+            if (g.launch(s, h)) return fail("bwd gemm 1 launch failed");
+        }
+        hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)B * D, 256)), dim3(256), 0, s, C0, ns1, st0, H + D, H, D, B, (const float*)nullptr, t.datt);
+        hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, C2, ns1, st2, H, 0, H, B, (const float*)nullptr, t.dg_t);
+        // dh1 so far = dh1_a + carry   (into dh_tot)
+        hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, C0, ns1, st0, H + D, 0, H, B, (const float*)t.dh1_c, t.dh_tot);
+        // new dh2 carry (hh part; the LSTM1-input part is added after GEMM 3)
+        hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, C1, ns1, st1, H, 0, H, B, (const float*)nullptr, t.dh2_c);
+        // attention
+        {
+            const size_t smem = (size_t)(R1 + 8) * sizeof(float);
+            hipLaunchKernelGGL(k_attend_bwd, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask,
+                               slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws);
+        }
+        // shift gate: dq into dpre1[:, 5H:6H], dtc
+        hipLaunchKernelGGL(k_gate2_bwd, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.dg_t, g1, (long long)6 * H, c1, B, H, dpre1 + 5 * H,
+                           (long long)6 * H, t.dtc);
+        // grouped GEMM 2: [dq | dhA] -> dh1_b ; [dsent | dsa] -> ds_t
+        {
+            GemmBuilder g;
+            GemmProb& p0 = g.prob(B, H, nullptr, H);
+            GemmBuilder::seg(p0, dpre1 + 5 * H, 6 * H, nullptr, t.wT_hg, H, H);
+            GemmBuilder::seg(p0, dhA, A, nullptr, t.wT_ha, A, A);
+            GemmProb& p1 = g.prob(B, H, nullptr, H);
+            GemmBuilder::seg(p1, dsent, D, nullptr, t.wT_sfc, D, D);
+            GemmBuilder::seg(p1, dsa, A, nullptr, t.wT_sa, A, A);
+            const int ns = g.finish(h);
+            const long long st = (long long)B * H;
+            float *Ca = t.scratch, *Cb = Ca + st * ns;
+            g.a.p[0].C = Ca; g.a.p[0].slab_stride = st;
+            g.a.p[1].C = Cb; g.a.p[1].slab_stride = st;
+            if (g.launch(s, h)) return fail("bwd gemm 2 launch failed");
+            hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, Ca, ns, st, H, 0, H, B, (const float*)t.dh_tot, t.dh_tot);
+            hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, Cb, ns, st, H, 0, H, B, (const float*)nullptr, t.ds_t);
+        }
+        // sentinel gate and LSTM1
+        hipLaunchKernelGGL(k_sgate_bwd, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.ds_t, g1, (long long)6 * H, c1, B, H, dpre1 + 4 * H,
+                           (long long)6 * H, t.dtc);
+        hipLaunchKernelGGL(k_lstm_bwd, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.dh_tot, t.dc1_c[cb], t.dtc, g1, (long long)6 * H, c1,
+                           tt > 0 ? c1p : (const float*)nullptr, B, H, dpre1, (long long)6 * H, t.dc1_c[cb ^ 1]);
+        // grouped GEMM 3: dpre1 -> dh2 carry (LSTM1 input part), dh1 carry
+        if (tt > 0) {
+            GemmBuilder g;
+            GemmProb& p1 = g.prob(B, H, nullptr, H);
+            GemmBuilder::seg(p1, dpre1, 6 * H, nullptr, t.wT_hh1, 4 * H, 4 * H);
+            GemmBuilder::seg(p1, dpre1 + 4 * H, 6 * H, nullptr, t.wT_hs, H, H);
+            if (d.h2_first_lstm) {
+                GemmProb& p0 = g.prob(B, H, nullptr, H);
+                GemmBuilder::seg(p0, dpre1, 6 * H, nullptr, t.wT_ih1, 4 * H, 4 * H);          // rows 0..H-1 of W_ih1^T = h2 columns
+                GemmBuilder::seg(p0, dpre1 + 4 * H, 6 * H, nullptr, t.wT_is, H, H);
+                GemmBuilder::seg(p0, dpre1 + 5 * H, 6 * H, nullptr, t.wT_ig, H, H);
+            }
+            const int ns = g.finish(h);
+            const long long st = (long long)B * H;
+            g.a.p[0].C = t.scratch; g.a.p[0].slab_stride = st;
+            if (d.h2_first_lstm) { g.a.p[1].C = t.scratch + st * ns; g.a.p[1].slab_stride = st; }
+            if (g.launch(s, h)) return fail("bwd gemm 3 launch failed");
+            hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.scratch, ns, st, H, 0, H, B, (const float*)nullptr, t.dh1_c);
+            if (d.h2_first_lstm)
+                hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.scratch + st * ns, ns, st, H, 0, H, B,
+                                   (const float*)t.dh2_c, t.dh2_c);
+        }
+        LAUNCHCHK();
+    }
+
+    // ---- phase B: weight gradients, reduction over all T*B rows
+    const float* h1prev = t.h1s;              // rows (t,b): state entering step t
+    const float* h1cur = t.h1s + BH;
+    const float* h2prev = t.h2s;
+    const float* h2cur = t.h2s + BH;
+    transpose(s, h2prev, H, TB, H, t.tX_h2prev, TBp);
+    transpose(s, t.x_all, E, TB, E, t.tX_x, TBp);
+    transpose(s, h1prev, H, TB, H, t.tX_h1prev, TBp);
+    transpose(s, h1cur, H, TB, H, t.tX_h1, TBp);
+    transpose(s, t.atts, D, TB, D, t.tX_att, TBp);
+    transpose(s, t.s_ts, H, TB, H, t.tX_st, TBp);
+    transpose(s, t.g_ts, H, TB, H, t.tX_gt, TBp);
+    transpose(s, h2cur, H, TB, H, t.tX_h2, TBp);
+    transpose(s, c.vbar, D, B, D, t.tX_vbar, Bp);
+    transpose(s, c.regions, D, RL, D, t.tX_reg, RLp);
+    transpose(s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp);
+    transpose(s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp);
+    transpose(s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp);
+    transpose(s, t.dhA_all, A, TB, A, t.tY_dhA, TBp);
+    transpose(s, t.dsent_all, D, TB, D, t.tY_dsent, TBp);
+    transpose(s, t.dsa_all, A, TB, A, t.tY_dsa, TBp);
+    transpose(s, t.dga_all, A, TB, A, t.tY_dga, TBp);
+    transpose(s, t.dP, A, RL, A, t.tY_dP, RLp);
+    hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 6 * H, 256)), dim3(256), 0, s, t.dpre1, T, (long long)B * 6 * H, t.dpre1sum);
+    transpose(s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
+    LAUNCHCHK();
+
+    // out_fc
+    if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H)) return 1;
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(V, 64)), dim3(256), 0, s, t.dlogits, (long long)Vp, TB, V, G[g_bout]);
+    // lstm_cell_2
+    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2)) return 1;
+    if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2)) return 1;
+    if (d.img_second_lstm) {
+        hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 4 * H, 256)), dim3(256), 0, s, t.dpre2, T, (long long)B * 4 * H, t.dpre2sum);
+        transpose(s, t.dpre2sum, 4 * H, B, 4 * H, t.tY_dpre2sum, Bp);
+        if (gemm_to1(h, t, s, 4 * H, D, Bp, t.tY_dpre2sum, Bp, t.tX_vbar, Bp, G[g_Wih2] + H + D, in2)) return 1;
+    }
+    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H)) return 1;
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(4 * H, 64)), dim3(256), 0, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2]);
+    HIPCHK(hipMemcpyAsync(G[g_bhh2], G[g_bih2], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // att_ga, W1_hg, att_ha, s_fc, att_sa
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H)) return 1;
+    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H)) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H)) return 1;
+    if (gemm_to1(h, t, s, D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H)) return 1;
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(D, 64)), dim3(256), 0, s, t.dsent_all, (long long)D, TB, D, G[g_bsfc]);
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H)) return 1;
+    // lstm_cell_1 / W1_is / W1_ig: row blocks [0,4H), [4H,5H), [5H,6H) of dpre1^T against [h2_prev | vbar | x]
+    {
+        float* Gw[3] = {G[g_Wih1], G[g_Wis], G[g_Wig]};
+        const int r0[3] = {0, 4 * H, 5 * H}, nr[3] = {4 * H, H, H};
+        for (int i = 0; i < 3; ++i) {
+            const float* dy = t.tY_dpre1 + (size_t)r0[i] * TBp;
+            if (d.h2_first_lstm && gemm_to1(h, t, s, nr[i], H, TBp, dy, TBp, t.tX_h2prev, TBp, Gw[i], in1)) return 1;
+            if (gemm_to1(h, t, s, nr[i], D, Bp, t.tY_dpre1sum + (size_t)r0[i] * Bp, Bp, t.tX_vbar, Bp, Gw[i] + voff, in1)) return 1;
+            if (gemm_to1(h, t, s, nr[i], E, TBp, dy, TBp, t.tX_x, TBp, Gw[i] + xoff, in1)) return 1;
+        }
+        if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H)) return 1;
+        if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H)) return 1;
+        hipLaunchKernelGGL(k_colsum, dim3(cdiv(4 * H, 64)), dim3(256), 0, s, t.dpre1, (long long)6 * H, TB, 4 * H, G[g_bih1]);
+        HIPCHK(hipMemcpyAsync(G[g_bhh1], G[g_bih1], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_colsum, dim3(cdiv(H, 64)), dim3(256), 0, s, t.dpre1 + 4 * H, (long long)6 * H, TB, H, G[g_bis]);
+        HIPCHK(hipMemcpyAsync(G[g_bhs], G[g_bis], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_colsum, dim3(cdiv(H, 64)), dim3(256), 0, s, t.dpre1 + 5 * H, (long long)6 * H, TB, H, G[g_big]);
+        HIPCHK(hipMemcpyAsync(G[g_bhg], G[g_big], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    // att_va: dP^T (A, RL) x regions^T (D, RL)
+    if (gemm_to1(h, t, s, A, D, RLp, t.tY_dP, RLp, t.tX_reg, RLp, G[g_Wva], D)) return 1;
+    // the three score vectors
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(A, 64)), dim3(256), 0, s, t.dwa_rows, (long long)A, TB, A, G[g_wa]);
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(A, 64)), dim3(256), 0, s, t.dws_rows, (long long)A, TB, A, G[g_ws]);
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(A, 64)), dim3(256), 0, s, t.dwg_rows, (long long)A, TB, A, G[g_wg]);
+    // embedding: dx = dpre1 . [W_ih1 ; W_is ; W_ig][:, x columns], scattered onto the rows that were looked up
+    {
+        SegSpec sg[3] = {{t.dpre1, 6 * H, t.wT_ih1 + (size_t)xoff * 4 * H, 4 * H, 4 * H},
+                         {t.dpre1 + 4 * H, 6 * H, t.wT_is + (size_t)xoff * H, H, H},
+                         {t.dpre1 + 5 * H, 6 * H, t.wT_ig + (size_t)xoff * H, H, H}};
+        if (gemm_to(h, t, s, TB, E, sg, 3, t.dx_all, E)) return 1;
+        HIPCHK(hipMemsetAsync(G[g_embed], 0, (size_t)V * E * sizeof(float), s));
+        hipLaunchKernelGGL(k_scatter_add_rows, dim3(cdiv((long long)TB * E, 256)), dim3(256), 0, s, t.dx_all, t.word32, TB, E, G[g_embed]);
+    }
+    LAUNCHCHK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- test hook
+// copies an internal training buffer (by name) into a caller tensor: lets the parity tests localise a gradient
+// mismatch to one stage instead of only seeing the 28 end results.
+extern "C" int vsr_debug_copy(vsr_handle* h, const char* name, float* dst, size_t n_floats, void* stream) {
+    if (!h || !name || !dst) return fail("vsr_debug_copy: null argument");
+    TrainCtx& t = *h->tc;
+    struct Ent { const char* n; const float* p; };
+    const Ent tab[] = {{"dh2_voc", t.dh2_voc}, {"dpre1", t.dpre1}, {"dpre2", t.dpre2}, {"gates1", t.gates1}, {"gates2", t.gates2},
+                       {"c1s", t.c1s}, {"c2s", t.c2s}, {"h1s", t.h1s}, {"h2s", t.h2s}, {"dlogits", t.dlogits}, {"alphas", t.alphas},
+                       {"dhA", t.dhA_all}, {"dsent", t.dsent_all}, {"dsa", t.dsa_all}, {"dga", t.dga_all}, {"dP", t.dP},
+                       {"atts", t.atts}, {"sents", t.sents}, {"wT_out", t.wT_out}, {"dx_all", t.dx_all}};
+    for (const Ent& e : tab)
+        if (!strcmp(e.n, name)) {
+            HIPCHK(hipMemcpyAsync(dst, e.p, n_floats * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            return 0;
+        }
+    return fail("vsr_debug_copy: unknown buffer '%s'", name);
+}

@@ -1,0 +1,324 @@
+// Backward (BPTT) kernels of the decoder step: the hand-written counterpart of what autograd derives from
+// /root/reference/models/controllable_captioning.py:117-190 when coco_scripts/train.py:112 calls loss.backward().
+// Every matrix product of the backward pass is run by the same fp32-MFMA "NT" GEMM (gemm_f32.h) on transposed
+// copies (weights once per step, activations / pre-activation gradients once per call); the kernels here are the
+// pointwise / reduction parts.  Notation: d<x> is dLoss/d<x>.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace vsr {
+
+// out (C, R) = in (R, C)^T, 32x32 tiles through LDS (both sides coalesced)
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, long long ld_in, int R, int C,
+                                                   float* __restrict__ out, long long ld_out) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) t[i][tx] = in[(long long)(r0 + i) * ld_in + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) out[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
+}
+
+// dst (rows, w) window with leading dimension ldd  =  sum of nslab compact (rows, w) slabs
+__global__ void k_slab_reduce_2d(const float* __restrict__ slabs, int nslab, long long stride, int rows, int w,
+                                 float* __restrict__ dst, long long ldd) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * w) return;
+    const int r = (int)(i / w), c = (int)(i % w);
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
+    dst[(long long)r * ldd + c] = s;
+}
+
+// column sums: out[c] = sum_r X[r][c]   (bias gradients); one block per 64 columns
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, long long ld, int R, int C, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int r = q; r < R; r += 4) s += X[(long long)r * ld + c];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < C) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// gather of embedding rows for all steps: x_all[(t*B+b)] = embed[word_in[b][t]]
+__global__ void k_gather_rows(const float* __restrict__ table, const int* __restrict__ idx, int rows, int E, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * E) return;
+    const int r = (int)(i / E), e = (int)(i % E);
+    out[i] = table[(long long)idx[r] * E + e];
+}
+// dEmbed[idx[r]] += dx[r]   (float atomics: rows may repeat inside a batch)
+__global__ void k_scatter_add_rows(const float* __restrict__ dx, const int* __restrict__ idx, int rows, int E, float* __restrict__ table_grad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * E) return;
+    const int r = (int)(i / E), e = (int)(i % E);
+    atomicAdd(table_grad + (long long)idx[r] * E + e, dx[i]);
+}
+
+// ---------------------------------------------------------------------------------------------- forward saves
+// LSTM1 + gates, training flavour: also stores the post-activation gates (B, 6H) = [i f g o s_gate .]
+__global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ vproj,
+                              const float* __restrict__ c1_old, int M, int H, float* __restrict__ h1n, float* __restrict__ c1n,
+                              float* __restrict__ s_t, float* __restrict__ gpre, float* __restrict__ gates) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * H) return;
+    const int row = (int)(i / H), j = (int)(i % H);
+    const long long base = (long long)row * 6 * H + j;
+    float q[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        q[g] = s + vproj[base + (long long)g * H];
+    }
+    const float ig = sigmoidf_(q[0]), fg = sigmoidf_(q[1]), gg = tanhf(q[2]), og = sigmoidf_(q[3]), sg = sigmoidf_(q[4]);
+    const float c = fg * c1_old[i] + ig * gg;
+    const float tc = tanhf(c);
+    h1n[i] = og * tc;
+    c1n[i] = c;
+    s_t[i] = sg * tc;
+    gpre[i] = q[5];
+    gates[base] = ig; gates[base + H] = fg; gates[base + 2LL * H] = gg; gates[base + 3LL * H] = og; gates[base + 4LL * H] = sg;
+}
+
+__global__ void k_lstm2_train(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ b_ih,
+                              const float* __restrict__ b_hh, const float* __restrict__ vproj2, const float* __restrict__ c2_old,
+                              int M, int H, float* __restrict__ h2n, float* __restrict__ c2n, float* __restrict__ gates) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * H) return;
+    const int row = (int)(i / H), j = (int)(i % H);
+    const long long base = (long long)row * 4 * H + j;
+    float q[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        s += b_ih[g * H + j] + b_hh[g * H + j];
+        if (vproj2) s += vproj2[base + (long long)g * H];
+        q[g] = s;
+    }
+    const float ig = sigmoidf_(q[0]), fg = sigmoidf_(q[1]), gg = tanhf(q[2]), og = sigmoidf_(q[3]);
+    const float c = fg * c2_old[i] + ig * gg;
+    h2n[i] = og * tanhf(c);
+    c2n[i] = c;
+    gates[base] = ig; gates[base + H] = fg; gates[base + 2LL * H] = gg; gates[base + 3LL * H] = og;
+}
+
+// reduce the att_ga slabs into ga (needed again by the backward pass)
+// (k_slab_reduce from kernels.h does it)
+
+// ---------------------------------------------------------------------------------------------- backward: outputs
+// dlogits = dlogp - exp(logp) * sum_v dlogp      (log_softmax backward, step :178), one block per row
+__global__ __launch_bounds__(256) void k_dlogits(const float* __restrict__ logp, const float* __restrict__ dlogp, int V,
+                                                 float* __restrict__ dlogits) {
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* g = dlogp + row * V;
+    const float* lp = logp + row * V;
+    float s = 0.f;
+    for (int v = tid; v < V; v += 256) s += g[v];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int v = tid; v < V; v += 256) dlogits[row * V + v] = g[v] - expf(lp[v]) * tot;
+}
+
+// gate log-softmax + z_g backward (:184-188): one wave per row.
+//   d[z_g, zsum] = dlg - exp(lg) * (dlg0 + dlg1);  z_g = w_g . tanh(ga + hA)
+// writes dga (M,A) = dz_g * w_g * (1 - th^2), adds the same into dhA, accumulates dw_g, returns dzsum per row
+__global__ __launch_bounds__(256) void k_gatelogit_bwd(const float* __restrict__ lg, const float* __restrict__ dlg, long long lg_stride,
+                                                       const float* __restrict__ ga, const float* __restrict__ hA,
+                                                       const float* __restrict__ w_g, int M, int A, float* __restrict__ dga,
+                                                       float* __restrict__ dhA, float* __restrict__ dzsum, float* __restrict__ dwg_rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float l0 = lg[row * lg_stride], l1 = lg[row * lg_stride + 1];
+    const float g0 = dlg[row * lg_stride], g1 = dlg[row * lg_stride + 1];
+    const float tot = g0 + g1;
+    const float dzg = g0 - expf(l0) * tot, dzs = g1 - expf(l1) * tot;
+    for (int a = lane; a < A; a += 64) {
+        const float th = tanhf(ga[(long long)row * A + a] + hA[(long long)row * A + a]);
+        const float du = dzg * w_g[a] * (1.f - th * th);
+        dga[(long long)row * A + a] = du;
+        dhA[(long long)row * A + a] = du;                 // first writer of dhA for this step
+        dwg_rows[(long long)row * A + a] = dzg * th;      // summed over rows later (k_colsum)
+    }
+    if (lane == 0) dzsum[row] = dzs;
+}
+
+// LSTM backward pointwise (used for both cells).  Inputs: dh (total gradient reaching h_t), dc_next (gradient reaching
+// c_t from step t+1), saved gates i,f,g,o (ld = gld, columns 0..4H), c_t, c_{t-1}; optional extra tanh(c) consumers:
+//   dtc_extra (gradient wrt tanh(c_t) from s_t / g_t paths, LSTM1 only).
+// Outputs: dpre (row, 4H) in columns [0,4H) of a (gld-wide) matrix, dc_prev.
+__global__ void k_lstm_bwd(const float* __restrict__ dh, const float* __restrict__ dc_next, const float* __restrict__ dtc_extra,
+                           const float* __restrict__ gates, long long gld, const float* __restrict__ c, const float* __restrict__ c_prev,
+                           int M, int H, float* __restrict__ dpre, long long dld, float* __restrict__ dc_prev) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * H) return;
+    const int row = (int)(i / H), j = (int)(i % H);
+    const float* g = gates + (long long)row * gld + j;
+    const float ig = g[0], fg = g[H], gg = g[2LL * H], og = g[3LL * H];
+    const float tc = tanhf(c[i]);
+    const float dhv = dh[i];
+    float dtc = dhv * og;
+    if (dtc_extra) dtc += dtc_extra[i];
+    const float dc = (dc_next ? dc_next[i] : 0.f) + dtc * (1.f - tc * tc);
+    float* d = dpre + (long long)row * dld + j;
+    d[0] = dc * gg * ig * (1.f - ig);
+    d[H] = dc * (c_prev ? c_prev[i] : 0.f) * fg * (1.f - fg);
+    d[2LL * H] = dc * ig * (1.f - gg * gg);
+    d[3LL * H] = dhv * tc * og * (1.f - og);
+    dc_prev[i] = dc * fg;
+}
+
+// attention backward (:158-171, :187), one 256-thread workgroup per row.
+//   att = a0 * sent + sum_r a_r X_r ;  a = (softmax(z) * m) / sum(softmax(z) * m) ;  zsum = sum_r m_r z_r
+//   z_r = w_a . tanh(P_r + hA) ;  z_0 = w_s . tanh(sa + hA)
+// in : datt (M,D), dzsum (M), alpha (M,R+1), saved hA, sa, sent; P, X, rmask of the row's (image, slot)
+// out: dsent (M,D) = a0 * datt; dsa (M,A); dhA (M,A) += ; dP[(image,slot)] (R,A) += ; per-row partials of dw_a, dw_s
+__global__ __launch_bounds__(256) void k_attend_bwd(const float* __restrict__ datt, const float* __restrict__ dzsum,
+                                                    const float* __restrict__ alpha, const float* __restrict__ hA,
+                                                    const float* __restrict__ sa, const float* __restrict__ sent,
+                                                    const float* __restrict__ P, const float* __restrict__ X,
+                                                    const float* __restrict__ rmask, const int* __restrict__ slot, int fixed_slot,
+                                                    int M, int L, int R, int A, int D, const float* __restrict__ w_a,
+                                                    const float* __restrict__ w_s, float* __restrict__ dsent, float* __restrict__ dsa,
+                                                    float* __restrict__ dhA, float* __restrict__ dP, float* __restrict__ dwa_rows,
+                                                    float* __restrict__ dws_rows) {
+    extern __shared__ float sm[];
+    float* da = sm;                 // R+1: dalpha, then dz
+    float* red = sm + R + 1;        // 8
+    const int row = xcd_item(M);
+    if (row < 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = slot ? slot[row] : fixed_slot;
+    const long long sl = (long long)row * L + k;
+    const float* g = datt + (long long)row * D;
+    const float* Xk = X + sl * R * D;
+    const float* al = alpha + (long long)row * (R + 1);
+    const float* mk = rmask + sl * R;
+    // dalpha_j = datt . regions_j   (wave w takes j = w, w+4, ...; masked rows have alpha = 0 and need no gradient)
+    for (int j = wave; j < R + 1; j += 4) {
+        float s = 0.f;
+        if (j == 0 || mk[j - 1] != 0.f) {
+            const float* src = (j == 0) ? sent + (long long)row * D : Xk + (long long)(j - 1) * D;
+            for (int d = lane * 4; d < D; d += 256) {
+                const float4 a = *reinterpret_cast<const float4*>(g + d);
+                const float4 b = *reinterpret_cast<const float4*>(src + d);
+                s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+            s = wave_sum(s);
+        }
+        if (lane == 0) da[j] = s;
+    }
+    // dsent = alpha_0 * datt
+    const float a0 = al[0];
+    for (int d = tid * 4; d < D; d += 1024) {
+        const float4 a = *reinterpret_cast<const float4*>(g + d);
+        *reinterpret_cast<float4*>(dsent + (long long)row * D + d) = make_float4(a0 * a.x, a0 * a.y, a0 * a.z, a0 * a.w);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // alpha = q / Q, q = s * m.  Recover s from alpha is not possible for masked entries (alpha = 0), but their
+        // softmax value only matters through sum_k ds_k s_k with ds_k = dq_k m_k = 0: masked entries drop out, and for
+        // unmasked ones s_j = alpha_j * Q with Q = sum of unmasked s.  Everything below is therefore in terms of alpha and Q:
+        //   dq_j = (dalpha_j - sum_k dalpha_k alpha_k) / Q ;  dz_j = s_j (dq_j m_j - sum_k dq_k m_k s_k)
+        //        = alpha_j Q [ (dalpha_j - S)/Q  - sum_k (dalpha_k - S)/Q * alpha_k Q ... ]   with S = sum dalpha alpha
+        // sum_k (dalpha_k - S) alpha_k = S - S = 0  =>  dz_j = alpha_j (dalpha_j - S)   for unmasked j, 0 for masked j.
+        float S = 0.f;
+        for (int j = lane; j < R + 1; j += 64) S += da[j] * al[j];
+        S = wave_sum(S);
+        const float dzs = dzsum[row];
+        for (int j = lane; j < R + 1; j += 64) {
+            float dz = al[j] * (da[j] - S);
+            if (j > 0) dz += mk[j - 1] * dzs;             // the shift logit sums the raw scores of the valid regions
+            da[j] = dz;
+        }
+    }
+    __syncthreads();
+    // du = dz * w * (1 - tanh^2(P + hA)); dP rows, dhA, dsa and the per-row partials of dw_a / dw_s
+    const float* Pk = P + sl * R * A;
+    float* dPk = dP + sl * R * A;
+    for (int a = tid; a < A; a += 256) {
+        const float h = hA[(long long)row * A + a];
+        const float wa = w_a[a];
+        float dh = 0.f, dwa = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float dz = da[r + 1];
+            if (dz != 0.f) {
+                const float th = tanhf(Pk[(long long)r * A + a] + h);
+                const float du = dz * wa * (1.f - th * th);
+                dPk[(long long)r * A + a] += du;           // a row visits its slots one step at a time: no race
+                dh += du;
+                dwa += dz * th;
+            }
+        }
+        const float ths = tanhf(sa[(long long)row * A + a] + h);
+        const float dus = da[0] * w_s[a] * (1.f - ths * ths);
+        dsa[(long long)row * A + a] = dus;
+        dhA[(long long)row * A + a] += dh + dus;
+        dwa_rows[(long long)row * A + a] = dwa;
+        dws_rows[(long long)row * A + a] = da[0] * ths;
+    }
+}
+
+// shift-gate vector backward (:181-182): g_t = gg * tanh(c1), gg = sigmoid(gpre + hg) saved in gates[:, 5H:6H]
+//   in dg_t; out dq (M,H) = dg_t * tc * gg (1 - gg)  [gradient of the gate pre-activation], dtc (M,H) = dg_t * gg
+__global__ void k_gate2_bwd(const float* __restrict__ dg_t, const float* __restrict__ gates, long long gld, const float* __restrict__ c1,
+                            int M, int H, float* __restrict__ dq, long long dq_ld, float* __restrict__ dtc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * H) return;
+    const int row = (int)(i / H), j = (int)(i % H);
+    const float tc = tanhf(c1[i]);
+    const float gg = gates[(long long)row * gld + 5LL * H + j];
+    const float d = dg_t[i];
+    dq[(long long)row * dq_ld + j] = d * tc * gg * (1.f - gg);
+    dtc[i] = d * gg;
+}
+
+// sentinel gate backward (:151-154): s_t = s_gate * tanh(c1):  ds_pre = ds_t * tc * sg (1 - sg); dtc += ds_t * sg
+__global__ void k_sgate_bwd(const float* __restrict__ ds_t, const float* __restrict__ gates, long long gld, const float* __restrict__ c1,
+                            int M, int H, float* __restrict__ ds_pre, long long ld, float* __restrict__ dtc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * H) return;
+    const int row = (int)(i / H), j = (int)(i % H);
+    const float sg = gates[(long long)row * gld + 4LL * H + j];
+    const float tc = tanhf(c1[i]);
+    const float d = ds_t[i];
+    ds_pre[(long long)row * ld + j] = d * tc * sg * (1.f - sg);
+    dtc[i] += d * sg;
+}
+
+// out = a + b (+ c)
+__global__ void k_add3(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + (b ? b[i] : 0.f) + (c ? c[i] : 0.f);
+}
+
+// strided variant for slab sums: out[r][c] = sum_k slabs[k][r][c0 + c] (+ add[r][c])
+__global__ void k_slab_cols(const float* __restrict__ slabs, int nslab, long long stride, int ld, int c0, int w, int rows,
+                            const float* __restrict__ add, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * w) return;
+    const int r = (int)(i / w), c = (int)(i % w);
+    float s = add ? add[i] : 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[k * stride + (long long)r * ld + c0 + c];
+    out[i] = s;
+}
+
+}  // namespace vsr

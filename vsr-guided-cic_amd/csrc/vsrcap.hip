@@ -25,6 +25,7 @@
 
 #include "gemm_f32.h"
 #include "kernels.h"
+#include "train_kernels.h"
 
 using namespace vsr;
 
@@ -61,7 +62,13 @@ struct Ctx {
     size_t scratch_floats = 0;
 };
 
+struct TrainCtx;
+static TrainCtx* new_train_ctx();
+static void free_train_ctx(TrainCtx*);
+static void invalidate_train_ctx(TrainCtx*);
+
 struct vsr_handle {
+    TrainCtx* tc = nullptr;
     vsr_dims d;
     vsr_weights w;
     bool bound = false, prepared = false;
@@ -198,6 +205,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("vsr_create: no HIP device");
     vsr_handle* h = new vsr_handle();
     h->d = d;
+    h->tc = new_train_ctx();
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
@@ -212,6 +220,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
 extern "C" void vsr_destroy(vsr_handle* h) {
     if (!h) return;
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    free_train_ctx(h->tc);
     delete h;
 }
 
@@ -288,6 +297,7 @@ extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R
     const size_t need = carve(h, c, reinterpret_cast<char*>(workspace));
     if (need > workspace_bytes) return fail("vsr_prepare: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
     h->prepared = false;
+    invalidate_train_ctx(h->tc);       // a saved forward refers to the hoisted tensors of the previous prepare()
 
     // pooled descriptor and region-row masks
     hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, s, det, R0, D, c.vbar);
@@ -415,7 +425,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         if (g.launch(s, h)) return fail("S2 gemm launch failed");
         const long long n = (long long)M * (H + A + D + A);
         hipLaunchKernelGGL(k_gate2, dim3(cdiv(n, 256)), dim3(256), 0, s, c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n,
-                           w.s_fc_bias, M, H, A, D, c.g_t, c.hA, c.sent, c.sa);
+                           w.s_fc_bias, M, H, A, D, c.g_t, c.hA, c.sent, c.sa, (float*)nullptr);
     }
     // ---- attention
     {
@@ -628,3 +638,10 @@ extern "C" int vsr_step(vsr_handle* h, int32_t t, int32_t rows_per_image, const 
     for (int j = 0; j < 4; ++j) HIPCHK(hipMemcpyAsync(out[j], c.st[1][j], n, hipMemcpyDeviceToDevice, s));
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------- training path
+#include "train.inc.h"
+
+static TrainCtx* new_train_ctx() { return new TrainCtx(); }
+static void free_train_ctx(TrainCtx* t) { delete t; }
+static void invalidate_train_ctx(TrainCtx* t) { if (t) t->valid = false; }

@@ -55,6 +55,10 @@ SIGNATURES = {
     "vsr_sample": (I32, [P, U64, P, P, P, P, P, P, P]),
     "vsr_beam": (I32, [P, I32, I32, I64, I64, P, I32, P, P, P, P, P, P]),
     "vsr_xe_forward": (I32, [P, P, I32, P, P, P]),
+    "vsr_train_workspace_bytes": (SZ, [P, I32, I32]),
+    "vsr_train_forward": (I32, [P, P, P, I32, P, P, P, SZ, P]),
+    "vsr_train_backward": (I32, [P, P, P, C.POINTER(VsrWeights), P]),
+    "vsr_debug_copy": (I32, [P, C.c_char_p, P, SZ, P]),
     "vsr_profile_begin": (I32, [P]),
     "vsr_profile_end": (I32, [P, P, C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double)]),
     "vsr_step": (I32, [P, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P]),

@@ -104,6 +104,38 @@ class Engine:
     def _stream(self, dev):
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
+    # ------------------------------------------------------------------ training (forward with saves + BPTT backward)
+    def train_forward(self, B, device, word_in, slots=None):
+        T = word_in.size(1)
+        V = self.dims.vocab_size
+        word_in = word_in.to(device=device, dtype=torch.int64).contiguous()
+        if slots is not None:
+            slots = slots.to(device=device, dtype=torch.int64).contiguous()
+        need = self.lib.vsr_train_workspace_bytes(self.h, B, T)
+        if need == 0:
+            raise RuntimeError("vsr_train_workspace_bytes rejected the shapes (prepare() first, same batch)")
+        if getattr(self, "_tws", None) is None or self._tws.numel() < need or self._tws.device != device:
+            self._tws = torch.empty(need, dtype=torch.uint8, device=device)
+        out = torch.empty(B, T, V, dtype=torch.float32, device=device)
+        gate = torch.empty(B, T, 2, dtype=torch.float32, device=device)
+        _lib.check(self.lib.vsr_train_forward(self.h, _ptr(word_in), _ptr(slots), T, _ptr(out), _ptr(gate), _ptr(self._tws),
+                                              self._tws.numel(), self._stream(device)))
+        return out, gate
+
+    def train_backward(self, device, grad_out, grad_gate, shapes):
+        """shapes: list of the 28 parameter shapes in WEIGHT_FIELDS order -> list of gradient tensors."""
+        grad_out = _f32(grad_out, "grad of word log-probs")
+        grad_gate = _f32(grad_gate, "grad of gate log-probs")
+        grads = [torch.empty(s, dtype=torch.float32, device=device) for s in shapes]
+        g = _lib.VsrWeights(*[t.data_ptr() for t in grads])
+        _lib.check(self.lib.vsr_train_backward(self.h, _ptr(grad_out), _ptr(grad_gate), C.byref(g), self._stream(device)))
+        return grads
+
+    def debug_buffer(self, name, shape, device):
+        out = torch.empty(shape, dtype=torch.float32, device=device)
+        _lib.check(self.lib.vsr_debug_copy(self.h, name.encode(), _ptr(out), out.numel(), self._stream(device)))
+        return out
+
     # ------------------------------------------------------------------ measurement
     def profile_begin(self):
         _lib.check(self.lib.vsr_profile_begin(self.h))
