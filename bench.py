@@ -55,16 +55,126 @@ def cpu_baseline(weights, sample_B, beam):
                        ("beam-%d" % beam if beam > 1 else "greedy", sample_B, c["T"], dt))
 
 
+def cpu_baseline_xe(weights, sample_B):
+    """XE step of coco_scripts/train.py:103-113 on the CPU oracle (autograd backward + Adam), bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vsr_oracle as vo
+    c = CFG
+    o = vo.Oracle(weights, c["T"], 2, as_written=True)
+    params = [o.p[k].requires_grad_(True) for k in o.p]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    det = torch.from_numpy(synth.make_detections(sample_B, c["R0"], c["D"], seed=77))
+    seq = torch.from_numpy(synth.make_ctrl(sample_B, c["T"], c["R"], c["D"], seed=78))
+    caps = torch.from_numpy(synth.make_captions(sample_B, c["T"], c["V"], seed=77))
+    gts = torch.from_numpy(synth.make_gate_gts(sample_B, c["T"], seed=77))
+    ts = []
+    for _ in range(2):
+        t0 = time.time()
+        opt.zero_grad()
+        out, gate = o.forward(det, caps, seq)
+        vo.xe_loss(out, gate, caps, gts)[0].backward()
+        opt.step()
+        ts.append(time.time() - t0)
+    return dict(value=sample_B / ts[-1], unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample="oracle/vsr_oracle.py as_written XE step (forward + NLL losses + autograd backward + Adam), %d images x %d steps, "
+                       "fp32, %.1f s (second of two steps)" % (sample_B, c["T"], ts[-1]))
+
+
+def train_bench(args):
+    """XE step (BASELINE configs[3]) / SCST step (configs[4]) in fp32: forward + losses + hand-written BPTT backward +
+    Adam, data-parallel over ranks with RCCL gradient all-reduce and global loss normalisation (vsrcap/parallel.py)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from models import ControllableCaptioningModel
+    from vsrcap import parallel
+    c = CFG
+    weights = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=0, gains={k: 1.0 for k in synth.DEFAULT_GAINS})
+    m = ControllableCaptioningModel(c["T"], c["V"], 2, det_feat_size=c["D"], input_encoding_size=c["E"], rnn_size=c["H"],
+                                    att_size=c["A"], verb_2_vob_all={})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    m = m.to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    xe = args.workload == "xe"
+    L = c["T"] if xe else c["L"]
+    batches = []
+    for i in range(2):
+        seed = 2000 + 10 * rank + i
+        batches.append((torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed)).to(dev),
+                        torch.from_numpy(synth.make_ctrl(c["B"], L, c["R"], c["D"], seed=seed)).to(dev),
+                        torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed)).to(dev),
+                        torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed)).to(dev)))
+    step = parallel.DataParallelStep(list(m.parameters()), opt, forward_fn=lambda d, cp, sq: m((d,), (cp, sq)),
+                                     sample_fn=lambda d, ct: m.sample_rl(d, ct))
+
+    def reward_fn(words):           # rewards are an INPUT of the RL step (CIDEr is out of scope): synthetic, on device
+        r = (words.sum(1) % 97).float() / 97.0
+        return r, torch.full_like(r, 0.5)
+
+    def one_step(i):
+        det, reg, caps, gts = batches[i & 1]
+        return step.xe_step(det, caps, reg, gts) if xe else step.scst_step(det, reg, reward_fn)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        one_step(i)
+    eng = m._engine(dev)
+    barrier()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_n, gemm_flops = eng.profile_end(dev)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        line = {
+            "metric": "XE-step samples/sec" if xe else "SCST-step samples/sec (1 sample/image, rewards given)",
+            "value": world * c["B"] * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("XE training step (forward + NLL losses + BPTT backward + Adam), batch 100/GPU, 20 slots x 36 regions x 2048-d, "
+                                    "seq_len 20, vocab 10000 (BASELINE configs[3], fp32)") if xe else
+                                   ("SCST step (sample_rl + replayed forward + BPTT backward + Adam), batch 100/GPU, 10 slots x 36 x 2048 "
+                                    "(BASELINE configs[4], fp32)"),
+                       "batch_per_gpu": c["B"], "seq_len": c["T"], "parallelism": "dp%d, RCCL gradient all-reduce" % world},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launches": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1), "gemm_share_of_wall": gemm_ms * 1e-3 / dt},
+        }
+        if world == 1 and not args.no_cpu and xe:
+            line["cpu_baseline"] = cpu_baseline_xe(weights, min(args.cpu_sample, 16))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="beam5", choices=["beam5", "greedy"])
+    ap.add_argument("--workload", default="beam5", choices=["beam5", "greedy", "xe", "scst"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24)
     args = ap.parse_args()
 
+    if args.workload in ("xe", "scst"):
+        return train_bench(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -1,0 +1,110 @@
+"""world-size-2 gloo tests (CPU) of the multi-GPU layer: shard arithmetic, id gathering, and
+"2 ranks == 1 rank on the concatenated batch" for the XE and SCST steps with UNEVEN shards and data-dependent
+ignore counts.  The per-rank compute is the CPU oracle here (tests may use it); on the GPU box the same
+DataParallelStep wraps the HIP model (bench.py --workload xe)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers
+import vsr_oracle as vo
+from vsrcap import parallel, synth
+
+CFG = dict(V=37, B=5, R0=6, R=5, D=64, L=4, T=6, E=16, H=24, A=12)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(cfg):
+    w = synth.make_weights(cfg["V"], cfg["D"], cfg["E"], cfg["H"], cfg["A"], seed=2, gains={k: 1.5 for k in synth.DEFAULT_GAINS})
+    o = vo.Oracle(w, cfg["T"], 2, as_written=False)
+    params = [o.p[k].requires_grad_(True) for k in o.p]
+    return o, params
+
+
+def _run_xe(o, params, det, caps, seq, gts, steps):
+    opt = torch.optim.Adam(params, lr=5e-4)
+    step = parallel.DataParallelStep(params, opt, forward_fn=lambda d, c, s: o.forward(d, c, s))
+    losses = [step.xe_step(det, caps, seq, gts) for _ in range(steps)]
+    return torch.stack(losses)
+
+
+def _reward(words):
+    r = (words.double().sum(1) % 7) / 7.0
+    return r.float(), torch.full_like(r, 0.4).float()
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg = CFG
+    det, seq, caps, gts = helpers.train_inputs(cfg, 9)
+    lo, hi = parallel.shard_bounds(cfg["B"], world, rank)
+    o, params = _make(cfg)
+    losses = _run_xe(o, params, det[lo:hi], caps[lo:hi], seq[lo:hi], gts[lo:hi], 2)
+    # SCST step on the decode inputs with replayed "samples" (deterministic: greedy tokens of the shard)
+    d2, c2 = helpers.decode_inputs(cfg, 10)
+    opt = torch.optim.Adam(params, lr=5e-4)
+
+    def sample_fn(d, c):
+        with torch.no_grad():
+            w_, g_ = o.test(d, c)
+        return o.sample_rl(d, c, forced=(w_, g_))
+    st = parallel.DataParallelStep(params, opt, sample_fn=sample_fn)
+    l_rl = st.scst_step(d2[lo:hi], c2[lo:hi], _reward)
+    ids = parallel.gather_ids(torch.arange(lo, hi)[:, None].repeat(1, 3), cfg["B"])
+    if rank == 0:
+        ret["losses"] = losses.numpy()
+        ret["rl"] = float(l_rl)
+        ret["ids"] = ids.numpy()
+        ret["params"] = {k: v.detach().numpy().copy() for k, v in o.p.items()}
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_everything():
+    for n, w in ((100, 8), (5, 2), (3, 4), (256, 8)):
+        spans = [parallel.shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert [b - a for a, b in (parallel.shard_bounds(100, 8, r) for r in range(8))] == [13, 13, 13, 13, 12, 12, 12, 12]
+
+
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    cfg = CFG
+    det, seq, caps, gts = helpers.train_inputs(cfg, 9)
+    o, params = _make(cfg)
+    ref = _run_xe(o, params, det, caps, seq, gts, 2).numpy()
+    d2, c2 = helpers.decode_inputs(cfg, 10)
+    opt = torch.optim.Adam(params, lr=5e-4)
+
+    def sample_fn(d, c):
+        with torch.no_grad():
+            w_, g_ = o.test(d, c)
+        return o.sample_rl(d, c, forced=(w_, g_))
+    ref_rl = float(parallel.DataParallelStep(params, opt, sample_fn=sample_fn).scst_step(d2, c2, _reward))
+    np.testing.assert_allclose(ret["losses"], ref, atol=1e-5, rtol=0)       # loss, loss_cap, loss_gate per step
+    assert abs(ret["rl"] - ref_rl) < 1e-6
+    for k, v in o.p.items():
+        np.testing.assert_allclose(ret["params"][k], v.detach().numpy(), atol=2e-6, rtol=1e-5, err_msg=k)
+    np.testing.assert_array_equal(ret["ids"][:, 0], np.arange(cfg["B"]))
+    # the gate targets really have a data-dependent number of ignored entries per shard
+    lo, hi = parallel.shard_bounds(cfg["B"], 2, 0)
+    assert (gts[lo:hi] == -1).sum() != (gts[hi:] == -1).sum()
