@@ -253,14 +253,30 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     }
     __syncthreads();
 
+    // weighted sum.  Rows with alpha == 0 (zero padding) are skipped: no HBM read for them.  Four region rows are in
+    // flight per thread (independent loads) so that the 8 KB rows stream instead of paying one L2/HBM latency each.
     const float* Xk = regions + sl * R * D;
     const float a0 = z_s[0];
     for (int d = tid * 4; d < D; d += 1024) {
         const float4 s = *reinterpret_cast<const float4*>(srow + d);
         float4 acc = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
-        for (int r = 0; r < R; ++r) {
+        int r = 0;
+        for (; r + 4 <= R; r += 4) {
+            const float al0 = z_s[r + 1], al1 = z_s[r + 2], al2 = z_s[r + 3], al3 = z_s[r + 4];
+            if (al0 == 0.f && al1 == 0.f && al2 == 0.f && al3 == 0.f) continue;
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 x0 = al0 != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + 0) * D + d) : z4;
+            const float4 x1 = al1 != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + 1) * D + d) : z4;
+            const float4 x2 = al2 != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + 2) * D + d) : z4;
+            const float4 x3 = al3 != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + 3) * D + d) : z4;
+            acc.x += al0 * x0.x; acc.y += al0 * x0.y; acc.z += al0 * x0.z; acc.w += al0 * x0.w;
+            acc.x += al1 * x1.x; acc.y += al1 * x1.y; acc.z += al1 * x1.z; acc.w += al1 * x1.w;
+            acc.x += al2 * x2.x; acc.y += al2 * x2.y; acc.z += al2 * x2.z; acc.w += al2 * x2.w;
+            acc.x += al3 * x3.x; acc.y += al3 * x3.y; acc.z += al3 * x3.z; acc.w += al3 * x3.w;
+        }
+        for (; r < R; ++r) {
             const float al = z_s[r + 1];
-            if (al != 0.f) {   // masked (zero) rows carry alpha == 0 exactly: skip their HBM read
+            if (al != 0.f) {
                 const float4 x = *reinterpret_cast<const float4*>(Xk + (long long)r * D + d);
                 acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
             }
@@ -362,12 +378,14 @@ __global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits,
                                                const int* __restrict__ forced, uint64_t seed, uint32_t t,
                                                const float* __restrict__ verbs, const int* __restrict__ slot, int rpi,
                                                int L, int gt, const int* __restrict__ vt_ptr,
-                                               const int* __restrict__ vt_ids, int n_verbs) {
+                                               const int* __restrict__ vt_ids, int n_verbs, int lds_row) {
     __shared__ float sv[256 * K];
     __shared__ int si[256 * K];
     __shared__ float red[8];
     __shared__ int redi[8];
     __shared__ int pick_s;
+    extern __shared__ float lrow[];          // V floats when the launch passes dynamic LDS: the combined row is
+    const bool use_lds = lds_row != 0;       // summed from the slabs ONCE and the later passes read it from LDS
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = logits + (long long)row * V;
@@ -421,15 +439,33 @@ __global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits,
     for (int q = 0; q < K; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
     float mx = -INFINITY;
     const int V4 = (V + 3) & ~3;
+    const bool vec = ((V & 3) == 0);
     for (int v0 = tid * 4; v0 < V4; v0 += 1024) {
         uint32_t rnd[4] = {0, 0, 0, 0};
         if (mode == VM_SAMPLE) Philox::gen(seed, (uint32_t)(v0 >> 2), (uint32_t)row, t, 0u, rnd);
+        float xs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + v0);
+            xs[0] = b4.x; xs[1] = b4.y; xs[2] = b4.z; xs[3] = b4.w;
+            for (int k = 0; k < nsplit; ++k) {
+                const float4 s4 = *reinterpret_cast<const float4*>(src + k * stride + v0);
+                xs[0] += s4.x; xs[1] += s4.y; xs[2] += s4.z; xs[3] += s4.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (v0 + e < V) {
+                    float x = bias[v0 + e];
+                    for (int k = 0; k < nsplit; ++k) x += src[k * stride + v0 + e];
+                    xs[e] = x;
+                }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int v = v0 + e;
             if (v < V) {
-                float x = bias[v];
-                for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
+                const float x = xs[e];
+                if (use_lds) lrow[v] = x;
                 mx = fmaxf(mx, x);
                 float key = x;
                 if (mode == VM_SAMPLE) key = x - logf(-logf(Philox::u01(rnd[e])));
@@ -454,31 +490,27 @@ __global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits,
     __syncthreads();
 
     // ---- pass 2: sum of exp
-    float se = 0.f;
-    for (int v = tid; v < V; v += 256) {
+    auto getx = [&](int v) {
+        if (use_lds) return lrow[v];
         float x = bias[v];
         for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
-        se += expf(x - mx);
-    }
+        return x;
+    };
+    float se = 0.f;
+    for (int v = tid; v < V; v += 256) se += expf(getx(v) - mx);
     se = wave_sum(se);
     if (lane == 0) red[4 + wave] = se;
     __syncthreads();
     const float lse = mx + logf((red[4] + red[5]) + (red[6] + red[7]));
 
     if (mode == VM_FULL) {
-        for (int v = tid; v < V; v += 256) {
-            float x = bias[v];
-            for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
-            full_out[(long long)row * full_stride + v] = x - lse;
-        }
+        for (int v = tid; v < V; v += 256) full_out[(long long)row * full_stride + v] = getx(v) - lse;
         return;
     }
     if (mode == VM_FORCED) {
         if (tid == 0) {
             const int id = forced[row];
-            float x = bias[id];
-            for (int k = 0; k < nsplit; ++k) x += src[k * stride + id];
-            top_v[row] = x - lse;
+            top_v[row] = getx(id) - lse;
             top_i[row] = id;
         }
         return;
@@ -509,9 +541,7 @@ __global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits,
         if (head < K && si[tid * K + head] == gi) ++head;
         if (tid == 0) {
             if (mode == VM_SAMPLE) {
-                float x = bias[gi];
-                for (int k = 0; k < nsplit; ++k) x += src[k * stride + gi];
-                top_v[row] = x - lse;
+                top_v[row] = getx(gi) - lse;
                 top_i[row] = gi;
             } else {
                 top_v[(long long)row * K + round] = gv - lse;

@@ -229,9 +229,11 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
             const long long stride = (long long)B * V;
             g.a.p[0].slab_stride = stride;
             if (g.launch(s, h)) return fail("train S6 gemm launch failed");
-            hipLaunchKernelGGL((k_vocab<1>), dim3(B), dim3(256), 0, s, c.scratch, ns, stride, w.out_fc_bias, B, V, (int)VM_FULL, c.top_v, c.top_i,
-                               logp_words + (size_t)tt * V, (long long)T * V, (const int*)nullptr, (uint64_t)0, (uint32_t)tt,
-                               (const float*)nullptr, slot, 1, c.L, 0, h->vt_ptr, h->vt_ids, h->n_verbs);
+            const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;
+            hipLaunchKernelGGL((k_vocab<1>), dim3(B), dim3(256), lds_row ? (size_t)V * sizeof(float) : 0, s, c.scratch, ns, stride,
+                               w.out_fc_bias, B, V, (int)VM_FULL, c.top_v, c.top_i, logp_words + (size_t)tt * V, (long long)T * V,
+                               (const int*)nullptr, (uint64_t)0, (uint32_t)tt, (const float*)nullptr, slot, 1, c.L, 0, h->vt_ptr, h->vt_ids,
+                               h->n_verbs, lds_row);
         }
         LAUNCHCHK();
     }

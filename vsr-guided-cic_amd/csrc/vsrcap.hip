@@ -187,6 +187,7 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+constexpr int VOCAB_LDS_MAX = 12288;    // 48 KB of dynamic LDS for the combined row
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------- API: lifetime
@@ -463,11 +464,13 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[0].slab_stride = stride;
         if (g.launch(s, h)) return fail("S6 gemm launch failed");
 #define VOCAB_ARGS c.scratch, ns, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
-                   io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs
-        if (io.K <= 1) hipLaunchKernelGGL((k_vocab<1>), dim3(M), dim3(256), 0, s, VOCAB_ARGS);
-        else if (io.K <= 2) hipLaunchKernelGGL((k_vocab<2>), dim3(M), dim3(256), 0, s, VOCAB_ARGS);
-        else if (io.K <= 4) hipLaunchKernelGGL((k_vocab<4>), dim3(M), dim3(256), 0, s, VOCAB_ARGS);
-        else hipLaunchKernelGGL((k_vocab<8>), dim3(M), dim3(256), 0, s, VOCAB_ARGS);
+                   io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row
+        const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;          // combined logits row staged in LDS (<= 96 KB)
+        const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
+        if (io.K <= 1) hipLaunchKernelGGL((k_vocab<1>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS);
+        else if (io.K <= 2) hipLaunchKernelGGL((k_vocab<2>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS);
+        else if (io.K <= 4) hipLaunchKernelGGL((k_vocab<4>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS);
+        else hipLaunchKernelGGL((k_vocab<8>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS);
 #undef VOCAB_ARGS
     }
     LAUNCHCHK();
