@@ -90,6 +90,14 @@ int vsr_bind_weights(vsr_handle* h, const vsr_weights* w);
  * vocab_ids[row_ptr[v] .. row_ptr[v+1]); verbs >= n_verbs have no entry.  DEVICE pointers, borrowed. */
 int vsr_set_verb_table(vsr_handle* h, const int32_t* row_ptr, const int32_t* vocab_ids, int32_t n_verbs);
 
+/* ---- decode cache (optional, inference) ----------------------------------------------------------------
+ * (V, 6H) projection of the embedding table through the x columns of lstm_cell_1.weight_ih / W1_is / W1_ig
+ * (step :147-152, :181): weight-only work, so it is hoisted out of the call.  The buffer is caller-owned and must
+ * outlive its use; vsr_bind_weights() or vsr_build_decode_cache(h, NULL, ...) drops it.  Rebuild after the
+ * weights change (the training calls never use it). */
+size_t vsr_decode_cache_floats(const vsr_handle* h);
+int vsr_build_decode_cache(vsr_handle* h, float* buffer, size_t n_floats, void* stream);
+
 /* ---- workspace ------------------------------------------------------------------------------------ */
 /* bytes needed for B images with L slots of R regions, R0 pooled regions, decoding with up to `beam`
  * hypotheses per image (1 for greedy / sampling / teacher forcing). */

@@ -113,19 +113,25 @@ __global__ void k_i32_to_i64(const int* src, int64_t* dst, int n) {
 // ---------------------------------------------------------------------------------------------- step
 // LSTM1 + sentinel gate + image part of the shift gate                                (step :151-154, :181)
 // pre: (nsplit, M, 6H) raw GEMM sums of [h2 | x | h1_old]; vproj: (B, 6H) hoisted vbar part + biases.
+// xproj (optional): (V, 6H) cached projection of every embedding row (decode cache), gathered by word[row];
+// nblk: number of leading gate blocks (of 6) that the GEMM produced (the rest only has hoisted terms).
 __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ vproj,
                         int rpi, const int* __restrict__ parent, const float* __restrict__ c1_old, int M, int H,
-                        float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre) {
+                        float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre,
+                        const float* __restrict__ xproj, const int* __restrict__ word, int nblk) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
     const long long base = (long long)row * 6 * H + j;
     const float* vp = vproj + (long long)(row / rpi) * 6 * H + j;
+    const float* xp = xproj ? xproj + (long long)word[row] * 6 * H + j : nullptr;
     float q[6];
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        if (g < nblk)
+            for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        if (xp) s += xp[(long long)g * H];
         q[g] = s + vp[(long long)g * H];
     }
     const int prow = parent ? parent[row] : row;

@@ -95,6 +95,8 @@ class ControllableCaptioningModel(CaptioningModel):
         if pdev.type != 'cuda' or (device.index is not None and pdev.index != device.index):
             raise RuntimeError("model parameters are on %s but the inputs are on %s" % (pdev, device))
         self._eng.bind(params)
+        # inference keeps a weight-only cache (embedding projection); while training the weights move every step
+        self._eng.decode_cache(pdev, self._weights_version(), enable=not self.training)
         return self._eng
 
     def _weights_version(self):

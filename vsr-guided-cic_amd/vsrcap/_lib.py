@@ -49,6 +49,8 @@ SIGNATURES = {
     "vsr_destroy": (None, [P]),
     "vsr_bind_weights": (I32, [P, C.POINTER(VsrWeights)]),
     "vsr_set_verb_table": (I32, [P, P, P, I32]),
+    "vsr_decode_cache_floats": (SZ, [P]),
+    "vsr_build_decode_cache": (I32, [P, P, SZ, P]),
     "vsr_workspace_bytes": (SZ, [P, I32, I32, I32, I32, I32]),
     "vsr_prepare": (I32, [P, P, I32, I32, P, I32, I32, I32, P, SZ, P]),
     "vsr_greedy": (I32, [P, P, I32, P, P, P]),

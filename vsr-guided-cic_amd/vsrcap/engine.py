@@ -58,6 +58,7 @@ class Engine:
             _lib.check(self.lib.vsr_bind_weights(self.h, C.byref(w)))
             self._bound_ptrs = ptrs
             self._prep_key = None
+            self._cache_key = None
         return ptrs
 
     def set_verb_table(self, table, device):
@@ -74,6 +75,22 @@ class Engine:
         fl = torch.tensor(flat if flat else [0], dtype=torch.int32, device=device)
         self._verb_dev = (rp, fl)
         _lib.check(self.lib.vsr_set_verb_table(self.h, _ptr(rp), _ptr(fl), n))
+
+    # ------------------------------------------------------------------ decode cache (inference only)
+    def decode_cache(self, device, weights_version, enable=True):
+        """(Re)build the embedding-projection cache when the weights changed; enable=False drops it (training)."""
+        key = (self._bound_ptrs, weights_version) if enable else None
+        if key == getattr(self, "_cache_key", None):
+            return
+        if not enable:
+            _lib.check(self.lib.vsr_build_decode_cache(self.h, C.c_void_p(0), 0, self._stream(device)))
+            self._cache_key = None
+            return
+        n = self.lib.vsr_decode_cache_floats(self.h)
+        if getattr(self, "_cache_buf", None) is None or self._cache_buf.numel() < n or self._cache_buf.device != device:
+            self._cache_buf = torch.empty(n, dtype=torch.float32, device=device)
+        _lib.check(self.lib.vsr_build_decode_cache(self.h, _ptr(self._cache_buf), self._cache_buf.numel(), self._stream(device)))
+        self._cache_key = key
 
     # ------------------------------------------------------------------ hoisted statics
     def prepare(self, det, regions, beam, weights_version=None):
