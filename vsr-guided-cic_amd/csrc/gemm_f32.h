@@ -72,10 +72,14 @@ constexpr int GEMM_LDS = GEMM_BK + 4;
 
 __device__ __host__ inline int gemm_range_begin(int g, int total, int G) { return (int)(((long long)g * total) / G); }
 
-template <int TM, int TN>      // 32x32 MFMA tiles per wave; workgroup tile = (64 TM) x (64 TN)
-__global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs args) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int LA = BM / 32, LB = BN / 32;            // float4 loads per thread per k-tile
+// TM x TN 32x32 MFMA tiles per wave, WM x WN waves per workgroup; workgroup tile = (32 TM WM) x (32 TN WN)
+template <int TM, int TN, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_f32_kernel(const GemmArgs args) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int LR = NT / 8;                           // tile rows covered by one load pass of the workgroup
+    constexpr int LA = BM / LR, LB = BN / LR;            // float4 loads per thread per k-tile
+    static_assert(BM % 64 == 0 && BM % LR == 0 && BN % LR == 0, "tile shape");
     __shared__ float smem[2 * (BM + BN) * GEMM_LDS];
     auto sA = [&](int buf) { return smem + buf * (BM + BN) * GEMM_LDS; };
     auto sB = [&](int buf) { return smem + buf * (BM + BN) * GEMM_LDS + BM * GEMM_LDS; };
@@ -89,9 +93,9 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs args) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, hh = lane >> 5;
-    const int lrow = tid >> 3;          // 0..31: 8 threads cover one 128-byte row segment
+    const int lrow = tid >> 3;          // 0..LR-1: 8 threads cover one 128-byte row segment
     const int lc4 = (tid & 7) * 4;      // float offset inside the k-tile
 
     // ------------------------------------------------------------------ load cursor (runs one iteration ahead)
@@ -110,14 +114,14 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs args) {
         l_seg_left = (S.K + GEMM_BK - 1) / GEMM_BK - first_tile;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            int m = m0 + lrow + 32 * i;
+            int m = m0 + lrow + LR * i;
             m = m < P.M ? m : P.M - 1;
             const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
             pa[i] = S.A + row * S.lda + lc4;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            int n = n0 + lrow + 32 * i;
+            int n = n0 + lrow + LR * i;
             n = n < P.N ? n : P.N - 1;
             pb[i] = S.W + (long long)n * S.ldw + lc4;
         }
@@ -161,10 +165,10 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs args) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LA; ++i)
-            *reinterpret_cast<float4*>(sA(buf) + (lrow + 32 * i) * GEMM_LDS + lc4) = ra[i];
+            *reinterpret_cast<float4*>(sA(buf) + (lrow + LR * i) * GEMM_LDS + lc4) = ra[i];
 #pragma unroll
         for (int i = 0; i < LB; ++i)
-            *reinterpret_cast<float4*>(sB(buf) + (lrow + 32 * i) * GEMM_LDS + lc4) = rb[i];
+            *reinterpret_cast<float4*>(sB(buf) + (lrow + LR * i) * GEMM_LDS + lc4) = rb[i];
     };
 
     // ------------------------------------------------------------------ compute-side tile bookkeeping
@@ -202,21 +206,27 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmArgs args) {
         const int extra = c_last ? args.nslab - 1 - c_piece : 0;     // unused slabs of a finished tile: zeros
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
         constexpr int TPR = BN / 4;                        // threads per staged row
-        constexpr int RPP = 256 / TPR;                     // rows per store pass
+        constexpr int RPP = NT / TPR;                      // rows per store pass
         const int c4 = (tid % TPR) * 4;
         const int n = n0 + c4;
 #pragma unroll
-        for (int ti = 0; ti < TM; ++ti) {                  // one 64-row band per pass (rows wm*32.. of tile-row ti)
+        for (int band = 0; band < BM / 64; ++band) {       // 64 tile rows per pass through the staging buffer
 #pragma unroll
-            for (int tj = 0; tj < TN; ++tj)
+            for (int ti = 0; ti < TM; ++ti) {
+                const int trow = wm * TM + ti;             // 32-row tile index of this wave's tile row ti
+                if ((trow >> 1) == band) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    stage[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e];
+                    for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            stage[((trow & 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e];
+                }
+            }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 64 / RPP; ++i) {
                 const int sr = tid / TPR + RPP * i;        // staged row 0..63
-                const int m = m0 + (sr >> 5) * (32 * TM) + ti * 32 + (sr & 31);
+                const int m = m0 + band * 64 + sr;
                 if (m < P.M && n < P.N) {
                     const float4 v = *reinterpret_cast<const float4*>(stage + sr * ST_LD + c4);
                     float* dst = C + (long long)m * P.ldc + n;

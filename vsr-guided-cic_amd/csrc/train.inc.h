@@ -104,6 +104,11 @@ static int gemm_to1(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, int
     SegSpec sg{A, lda, W, ldw, K};
     return gemm_to(h, t, s, M, N, &sg, 1, dst, ldd);
 }
+// deterministic two-stage column sum through the (idle) slab scratch
+static void colsum(TrainCtx& t, hipStream_t s, const float* X, long long ld, int R, int C, float* out) {
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), COLSUM_CHUNKS), dim3(256), 0, s, X, ld, R, C, t.scratch);
+    hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(C, 256)), dim3(256), 0, s, t.scratch, C, out);
+}
 static void transpose(hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out) {
     hipLaunchKernelGGL(k_transpose, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, in, ld_in, R, C, out, ld_out);
 }
@@ -453,7 +458,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
 
     // out_fc
     if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H)) return 1;
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(V, 64)), dim3(256), 0, s, t.dlogits, (long long)Vp, TB, V, G[g_bout]);
+    colsum(t, s, t.dlogits, (long long)Vp, TB, V, G[g_bout]);
     // lstm_cell_2
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2)) return 1;
     if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2)) return 1;
@@ -463,14 +468,14 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         if (gemm_to1(h, t, s, 4 * H, D, Bp, t.tY_dpre2sum, Bp, t.tX_vbar, Bp, G[g_Wih2] + H + D, in2)) return 1;
     }
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H)) return 1;
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(4 * H, 64)), dim3(256), 0, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2]);
+    colsum(t, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2]);
     HIPCHK(hipMemcpyAsync(G[g_bhh2], G[g_bih2], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     // att_ga, W1_hg, att_ha, s_fc, att_sa
     if (gemm_to1(h, t, s, A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H)) return 1;
     if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H)) return 1;
     if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H)) return 1;
     if (gemm_to1(h, t, s, D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H)) return 1;
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(D, 64)), dim3(256), 0, s, t.dsent_all, (long long)D, TB, D, G[g_bsfc]);
+    colsum(t, s, t.dsent_all, (long long)D, TB, D, G[g_bsfc]);
     if (gemm_to1(h, t, s, A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H)) return 1;
     // lstm_cell_1 / W1_is / W1_ig: row blocks [0,4H), [4H,5H), [5H,6H) of dpre1^T against [h2_prev | vbar | x]
     {
@@ -484,19 +489,19 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         }
         if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H)) return 1;
         if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H)) return 1;
-        hipLaunchKernelGGL(k_colsum, dim3(cdiv(4 * H, 64)), dim3(256), 0, s, t.dpre1, (long long)6 * H, TB, 4 * H, G[g_bih1]);
+        colsum(t, s, t.dpre1, (long long)6 * H, TB, 4 * H, G[g_bih1]);
         HIPCHK(hipMemcpyAsync(G[g_bhh1], G[g_bih1], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_colsum, dim3(cdiv(H, 64)), dim3(256), 0, s, t.dpre1 + 4 * H, (long long)6 * H, TB, H, G[g_bis]);
+        colsum(t, s, t.dpre1 + 4 * H, (long long)6 * H, TB, H, G[g_bis]);
         HIPCHK(hipMemcpyAsync(G[g_bhs], G[g_bis], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_colsum, dim3(cdiv(H, 64)), dim3(256), 0, s, t.dpre1 + 5 * H, (long long)6 * H, TB, H, G[g_big]);
+        colsum(t, s, t.dpre1 + 5 * H, (long long)6 * H, TB, H, G[g_big]);
         HIPCHK(hipMemcpyAsync(G[g_bhg], G[g_big], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     // att_va: dP^T (A, RL) x regions^T (D, RL)
     if (gemm_to1(h, t, s, A, D, RLp, t.tY_dP, RLp, t.tX_reg, RLp, G[g_Wva], D)) return 1;
     // the three score vectors
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(A, 64)), dim3(256), 0, s, t.dwa_rows, (long long)A, TB, A, G[g_wa]);
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(A, 64)), dim3(256), 0, s, t.dws_rows, (long long)A, TB, A, G[g_ws]);
-    hipLaunchKernelGGL(k_colsum, dim3(cdiv(A, 64)), dim3(256), 0, s, t.dwg_rows, (long long)A, TB, A, G[g_wg]);
+    colsum(t, s, t.dwa_rows, (long long)A, TB, A, G[g_wa]);
+    colsum(t, s, t.dws_rows, (long long)A, TB, A, G[g_ws]);
+    colsum(t, s, t.dwg_rows, (long long)A, TB, A, G[g_wg]);
     // embedding: dx = dpre1 . [W_ih1 ; W_is ; W_ig][:, x columns], scattered onto the rows that were looked up
     {
         SegSpec sg[3] = {{t.dpre1, 6 * H, t.wT_ih1 + (size_t)xoff * 4 * H, 4 * H, 4 * H},

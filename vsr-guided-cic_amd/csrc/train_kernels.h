@@ -35,16 +35,28 @@ __global__ void k_slab_reduce_2d(const float* __restrict__ slabs, int nslab, lon
     dst[(long long)r * ldd + c] = s;
 }
 
-// column sums: out[c] = sum_r X[r][c]   (bias gradients); one block per 64 columns
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, long long ld, int R, int C, float* __restrict__ out) {
+// column sums: out[c] = sum_r X[r][c]   (bias gradients).  Two deterministic stages: grid (C/64, NCH) blocks each sum
+// a chunk of rows into part[chunk][c], then k_colsum_finish adds the NCH partials in order.
+constexpr int COLSUM_CHUNKS = 32;
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, long long ld, int R, int C, float* __restrict__ part) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int per = (R + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
+    const int r0 = blockIdx.y * per, r1 = min(R, r0 + per);
     float s = 0.f;
     if (c < C)
-        for (int r = q; r < R; r += 4) s += X[(long long)r * ld + c];
+        for (int r = r0 + q; r < r1; r += 4) s += X[(long long)r * ld + c];
     red[q][threadIdx.x & 63] = s;
     __syncthreads();
-    if (q == 0 && c < C) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (q == 0 && c < C)
+        part[(long long)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void k_colsum_finish(const float* __restrict__ part, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < COLSUM_CHUNKS; ++k) s += part[(long long)k * C + c];
+    out[c] = s;
 }
 
 __global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, long long n) {
@@ -212,17 +224,30 @@ __global__ __launch_bounds__(256) void k_attend_bwd(const float* __restrict__ da
     const float* Xk = X + sl * R * D;
     const float* al = alpha + (long long)row * (R + 1);
     const float* mk = rmask + sl * R;
-    // dalpha_j = datt . regions_j   (wave w takes j = w, w+4, ...; masked rows have alpha = 0 and need no gradient)
+    // dalpha_j = datt . regions_j   (wave w takes j = w, w+4, ...; masked rows have alpha = 0 and need no gradient).
+    // All eight 16-byte loads of a row are issued before the first use (independent accumulators).
     for (int j = wave; j < R + 1; j += 4) {
         float s = 0.f;
         if (j == 0 || mk[j - 1] != 0.f) {
             const float* src = (j == 0) ? sent + (long long)row * D : Xk + (long long)(j - 1) * D;
-            for (int d = lane * 4; d < D; d += 256) {
+            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+            int d = lane * 4;
+            for (; d + 768 < D; d += 1024) {
+                const float4 b0 = *reinterpret_cast<const float4*>(src + d), b1 = *reinterpret_cast<const float4*>(src + d + 256);
+                const float4 b2 = *reinterpret_cast<const float4*>(src + d + 512), b3 = *reinterpret_cast<const float4*>(src + d + 768);
+                const float4 a0 = *reinterpret_cast<const float4*>(g + d), a1 = *reinterpret_cast<const float4*>(g + d + 256);
+                const float4 a2 = *reinterpret_cast<const float4*>(g + d + 512), a3 = *reinterpret_cast<const float4*>(g + d + 768);
+                p0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+                p1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+                p2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
+                p3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
+            }
+            for (; d < D; d += 256) {
                 const float4 a = *reinterpret_cast<const float4*>(g + d);
                 const float4 b = *reinterpret_cast<const float4*>(src + d);
-                s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+                p0 += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
             }
-            s = wave_sum(s);
+            s = wave_sum((p0 + p1) + (p2 + p3));
         }
         if (lane == 0) da[j] = s;
     }
