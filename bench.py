@@ -31,6 +31,21 @@ EOS = 3
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 
 
+def measured_traffic():
+    """HBM bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
+    command, FETCH_SIZE doubled per the guide's gfx950 correction); None when no profile has been committed."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("gemm_hbm_traffic.json"):
+                try:
+                    best = json.load(open(os.path.join(pdir, f)))["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
+    return best
+
+
 def cpu_baseline(weights, sample_B, beam):
     """The CPU oracle in its as-written flavour (the reference's cost profile: per-step recompute of the pooled
     descriptor / region projection, statics re-gather per beam step, full sort) on a bounded sample."""
@@ -241,8 +256,9 @@ def main():
                        "beam": beam, "batch_per_gpu": c["B"], "seq_len": c["T"], "parallelism": "images sharded, dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "launches": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
-                         "gemm_share_of_wall": gemm_ms * 1e-3 / dt},
+                         "traffic": measured_traffic() if beam > 1 else None, "launches": gemm_n,
+                         "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1), "gemm_share_of_wall": gemm_ms * 1e-3 / dt,
+                         "algorithmic_flops_per_launch": gemm_flops / max(gemm_n, 1)},
         }
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam)
