@@ -269,3 +269,24 @@ def test_eos_on_both_streams_freezes_hypotheses():
         B = eng.prepare(det.to(DEV), ctrl.to(DEV), 3, m._weights_version())
         (w_, g_), (lw, lg), sc = eng.beam(B, torch.device(DEV), 3, 1, eos[0], eos[1])
     np.testing.assert_allclose(sc[:, 0].cpu().numpy(), osc[:, 0].numpy(), atol=1e-4, rtol=0)
+
+
+def test_eval_side_batching_equals_per_image_calls():
+    """one beam_search_v call for all images of an eval batch == the reference's per-image calls."""
+    from vsrcap import synth
+    from vsrcap.evalbatch import beam_search_v_batched
+    meta, _ = load_golden("g3_beam_small")
+    cfg = meta["cfg"]
+    m, _ = _model_for(meta, table=meta["verb_table"])
+    items = []
+    for i, n_caps in enumerate((3, 5, 1, 4)):
+        det_i = torch.from_numpy(synth.make_detections(1, cfg["R0"], cfg["D"], seed=40 + i))[0].to(DEV)
+        seq_i = torch.from_numpy(synth.make_ctrl(n_caps, cfg["L"], cfg["R"], cfg["D"], seed=50 + i)).to(DEV)
+        verbs_i = torch.from_numpy(synth.make_verbs(n_caps, cfg["L"], meta["nv"], seed=60 + i, p=0.3)).to(DEV)
+        items.append((det_i, seq_i, verbs_i))
+    with torch.no_grad():
+        batched = beam_search_v_batched(m, items, meta["eos"], beam_size=5, out_size=1, gt=False)
+        for (det_i, seq_i, verbs_i), (outs, _) in zip(items, batched):
+            d = det_i.unsqueeze(0).expand(seq_i.size(0), -1, -1).contiguous()
+            (w1, g1), _ = m.beam_search_v((d, seq_i, verbs_i), meta["eos"], 5, 1, gt=False)
+            assert (outs[0] == w1).all() and (outs[1] == g1).all()
