@@ -73,8 +73,19 @@ constexpr int GEMM_LDS = GEMM_BK + 4;
 __device__ __host__ inline int gemm_range_begin(int g, int total, int G) { return (int)(((long long)g * total) / G); }
 
 // TM x TN 32x32 MFMA tiles per wave, WM x WN waves per workgroup; workgroup tile = (32 TM WM) x (32 TN WN)
+// Occupancy is LDS-bound (160 KB / (2 (BM + BN) 36 4 B) workgroups per CU); telling the register allocator so
+// keeps it from spilling the in-flight tile to scratch in pursuit of waves the LDS could never host.
+constexpr int gemm_waves_per_eu(int TM, int TN, int WM, int WN) {
+    const int lds = 2 * (32 * TM * WM + 32 * TN * WN) * 36 * 4;
+    const int wgs = 163840 / lds;
+    const int w = wgs * WM * WN / 4;
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+
 template <int TM, int TN, int WM = 2, int WN = 2>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_f32_kernel(const GemmArgs args) {
+__global__ __launch_bounds__(64 * WM * WN)
+__attribute__((amdgpu_waves_per_eu(gemm_waves_per_eu(TM, TN, WM, WN), gemm_waves_per_eu(TM, TN, WM, WN))))
+void gemm_nt_f32_kernel(const GemmArgs args) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LR = NT / 8;                           // tile rows covered by one load pass of the workgroup
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_f32_kernel(const GemmArg
     const float* pb[LB];
     int l_prob = 0, l_tile = 0, l_tile_left = 0;          // problem, local tile id, k-tiles left in the tile
     int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;      // segment, k-tiles left in it, next k, its K
-    auto open_segment = [&](int s, int first_tile) {
+    auto open_segment = [&](int s, int first_tile) __attribute__((always_inline)) {
         const GemmProb& P = args.p[l_prob];
         const GemmSeg& S = P.seg[s];
         const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
@@ -126,7 +137,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_f32_kernel(const GemmArg
             pb[i] = S.W + (long long)n * S.ldw + lc4;
         }
     };
-    auto open_tile = [&](int prob, int tile, int kt) {     // position the cursor on k-tile kt of a tile
+    auto open_tile = [&](int prob, int tile, int kt) __attribute__((always_inline)) {     // position the cursor on k-tile kt of a tile
         l_prob = prob;
         l_tile = tile;
         const GemmProb& P = args.p[prob];
@@ -135,14 +146,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_f32_kernel(const GemmArg
         while (s < P.nseg - 1 && kt >= (P.seg[s].K + GEMM_BK - 1) / GEMM_BK) { kt -= (P.seg[s].K + GEMM_BK - 1) / GEMM_BK; ++s; }
         open_segment(s, kt);
     };
-    auto load_next = [&]() {
+    auto load_next = [&]() __attribute__((always_inline)) {
         if (l_tile_left == 0) {                            // wave-uniform, once per tile
             if (l_tile + 1 < args.p[l_prob].tiles_m * args.p[l_prob].tiles_n) open_tile(l_prob, l_tile + 1, 0);
             else open_tile(l_prob + 1, 0, 0);
         } else if (l_seg_left == 0) {
             open_segment(l_seg + 1, 0);
         }
-        const bool kin = l_k + lc4 < l_K;                  // K tail: read a valid address, use zeros
+        const bool kin = l_k + lc4 < l_K;                  // K tail: read a valid address, store zeros
 #if defined(GEMM_L1HOT)
         const int ko = 0;                                  // diagnostics: every k-tile re-reads the same (L1-resident) lines
 #else
@@ -152,17 +163,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_f32_kernel(const GemmArg
         for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(pa[i] + ko);
 #pragma unroll
         for (int i = 0; i < LB; ++i) rb[i] = *reinterpret_cast<const float4*>(pb[i] + ko);
-        if (!kin) {
+        // The tail is zeroed when the tile is written to LDS, NOT here: touching the load destinations now would
+        // put an s_waitcnt right behind the loads (hipcc hoisted a vmcnt(4) out of the branch: one exposed L2
+        // round trip per k-step).  store_tile() re-derives the tail predicate from the cursor (l_k has advanced by BK).
+        l_k += GEMM_BK;
+        --l_seg_left;
+        --l_tile_left;
+    };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        if (!(l_k - GEMM_BK + lc4 < l_K)) {                // K tail of the tile in flight (l_k has advanced by BK): zeros
 #pragma unroll
             for (int i = 0; i < LA; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int i = 0; i < LB; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        l_k += GEMM_BK;
-        --l_seg_left;
-        --l_tile_left;
-    };
-    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LA; ++i)
             *reinterpret_cast<float4*>(sA(buf) + (lrow + LR * i) * GEMM_LDS + lc4) = ra[i];
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_f32_kernel(const GemmArg
     // ------------------------------------------------------------------ compute-side tile bookkeeping
     int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0;   // iterations left before this tile's piece is flushed
     bool c_last = false;                                   // this piece completes the tile
-    auto decode = [&](int it) {                            // global iteration -> tile, piece, #iterations here
+    auto decode = [&](int it) __attribute__((always_inline)) {                            // global iteration -> tile, piece, #iterations here
         int p = 0;
 #pragma unroll
         for (int i = 1; i < 4; ++i)
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_f32_kernel(const GemmArg
     // leaves as 4 x 16-byte stores per thread (full 256-byte rows) instead of 16 dword stores with per-element
     // address arithmetic; unused slabs of a finished tile get zeros the same way.
     constexpr int ST_LD = BN + 4;
-    auto flush = [&](const f32x16 (&acc)[TM][TN], float* stage) {
+    auto flush = [&](const f32x16 (&acc)[TM][TN], float* stage) __attribute__((always_inline)) {
         const GemmProb& P = args.p[c_prob];
         const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
         float* C = P.C + (long long)c_piece * P.slab_stride;
