@@ -290,3 +290,56 @@ def test_eval_side_batching_equals_per_image_calls():
             d = det_i.unsqueeze(0).expand(seq_i.size(0), -1, -1).contiguous()
             (w1, g1), _ = m.beam_search_v((d, seq_i, verbs_i), meta["eos"], 5, 1, gt=False)
             assert (outs[0] == w1).all() and (outs[1] == g1).all()
+
+
+def test_bitwise_determinism_and_stream_independence(full_model):
+    """stream-K partial sums are added in slab order (no atomics): two runs - also on a side stream - give the
+    same bits, for tokens and for the returned log-probs / scores."""
+    meta, m, _, det, ctrl = full_model
+    d, c = det[:64].contiguous(), ctrl[:64].contiguous()
+    with torch.no_grad():
+        (w1, g1), (l1, _) = m.beam_search((d, c), meta["eos"], 5, 2)
+        (w2, g2), (l2, _) = m.beam_search((d, c), meta["eos"], 5, 2)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            (w3, g3), (l3, _) = m.beam_search((d, c), meta["eos"], 5, 2)
+        torch.cuda.current_stream().wait_stream(s)
+    assert torch.equal(w1, w2) and torch.equal(g1, g2) and torch.equal(l1, l2)
+    assert torch.equal(w1, w3) and torch.equal(g1, g3) and torch.equal(l1, l3)
+
+
+def test_large_vocabulary_takes_the_global_memory_row_path():
+    """V above the LDS staging limit (12288 rows) exercises k_vocab's re-read path; V % 4 != 0 the scalar path."""
+    import vsr_oracle as vo
+    from vsrcap import synth
+    cfg = dict(V=12301, B=3, R0=4, R=5, D=64, L=3, T=4, E=32, H=32, A=16)
+    w = synth.make_weights(cfg["V"], cfg["D"], cfg["E"], cfg["H"], cfg["A"], seed=6)
+    m = helpers.build_model(cfg, w, DEV)
+    o = vo.Oracle(w, cfg["T"], 2, as_written=False)
+    det, ctrl = helpers.decode_inputs(cfg, 33)
+    with torch.no_grad():
+        ow, og = o.test(det, ctrl)
+        w_, g_ = m.test(det.to(DEV), ctrl.to(DEV))
+        (obw, obg), _ = o.beam_search(det, ctrl, [3, -1], 3, 1)
+        (bw, bg), _ = m.beam_search((det.to(DEV), ctrl.to(DEV)), [3, -1], 3, 1)
+    np.testing.assert_array_equal(w_.cpu().numpy(), ow.numpy())
+    np.testing.assert_array_equal(bw.cpu().numpy(), obw.numpy())
+    np.testing.assert_array_equal(bg.cpu().numpy(), obg.numpy())
+
+
+def test_teacher_forcing_step_matches_forward():
+    """step(mode='teacher_forcing') driven manually (as CaptioningModel.forward does, :30-32) == forward()."""
+    meta, g = load_golden("g1_xe_small")
+    cfg = meta["cfg"]
+    m, _ = _model_for(meta, gains=meta["gains"])
+    det, ctrl_seq, caps, _ = helpers.train_inputs(cfg, meta["seed"])
+    det, ctrl_seq, caps = det.to(DEV), ctrl_seq.to(DEV), caps.to(DEV)
+    with torch.no_grad():
+        out, gate = m((det,), (caps, ctrl_seq))
+        state = m.init_state(cfg["B"], torch.device(DEV))
+        outs = None
+        for t in range(3):
+            outs, state = m.step(t, state, outs, (det,), (caps, ctrl_seq), mode="teacher_forcing")
+            np.testing.assert_allclose(outs[0].cpu().numpy(), out[:, t].cpu().numpy(), atol=2e-5, rtol=0)
+            np.testing.assert_allclose(outs[1].cpu().numpy(), gate[:, t].cpu().numpy(), atol=2e-5, rtol=0)
