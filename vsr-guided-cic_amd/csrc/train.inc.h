@@ -21,6 +21,7 @@ struct TrainCtx {
     float *gates1, *gates2, *s_ts, *g_ts, *hAs, *sas, *gas, *sents, *atts, *alphas, *x_all;
     int *word32, *slot32;
     float *dlogits, *dh2_voc, *dpre1, *dpre2, *dhA_all, *dsent_all, *dsa_all, *dga_all, *dwa_rows, *dws_rows, *dwg_rows, *dP;
+    float *dalpha;
     float *datt, *dg_t, *dtc, *ds_t, *dh_tot, *dzsum, *dh1_c, *dh2_c, *dc1_c[2], *dc2_c[2], *dpre1sum, *dpre2sum, *dx_all;
     float *wT_ih1, *wT_is, *wT_ig, *wT_hh1, *wT_hs, *wT_ih2, *wT_hh2, *wT_hg, *wT_ha, *wT_sfc, *wT_sa, *wT_ga, *wT_out;
     float *tX_h2prev, *tX_x, *tX_h1prev, *tX_h1, *tX_att, *tX_st, *tX_gt, *tX_h2, *tX_vbar, *tX_reg;
@@ -57,7 +58,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.dwa_rows = b.take<float>(TB * A); t.dws_rows = b.take<float>(TB * A); t.dwg_rows = b.take<float>(TB * A);
     t.dP = b.take<float>(RL * A);
     t.datt = b.take<float>(B * D); t.dg_t = b.take<float>(B * H); t.dtc = b.take<float>(B * H); t.ds_t = b.take<float>(B * H);
-    t.dh_tot = b.take<float>(B * H); t.dzsum = b.take<float>(B);
+    t.dh_tot = b.take<float>(B * H); t.dzsum = b.take<float>(B); t.dalpha = b.take<float>(B * R1);
     t.dh1_c = b.take<float>(B * H); t.dh2_c = b.take<float>(B * H);
     for (int i = 0; i < 2; ++i) { t.dc1_c[i] = b.take<float>(B * H); t.dc2_c[i] = b.take<float>(B * H); }
     t.dpre1sum = b.take<float>(B * 6 * H); t.dpre2sum = b.take<float>(B * 4 * H); t.dx_all = b.take<float>(TB * E);
@@ -375,7 +376,9 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         // attention
         {
             const size_t smem = (size_t)(R1 + 8) * sizeof(float);
-            hipLaunchKernelGGL(k_attend_bwd, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask,
+            hipLaunchKernelGGL(k_dalpha, dim3(cdiv((long long)B * R1, 4)), dim3(256), 0, s, t.datt, sent, c.regions, c.rmask, slot, B, c.L, c.R, D,
+                               t.dalpha);
+            hipLaunchKernelGGL(k_attend_bwd, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask,
                                slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws);
         }
         // shift gate: dq into dpre1[:, 5H:6H], dtc

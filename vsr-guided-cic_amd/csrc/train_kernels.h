@@ -198,12 +198,48 @@ __global__ void k_lstm_bwd(const float* __restrict__ dh, const float* __restrict
     dc_prev[i] = dc * fg;
 }
 
+// dalpha[row][j] = datt[row] . regions_j  (j = 0: sentinel), one WAVE per (row, j): B x (R+1) independent dot products
+// over D, so that a training batch of 100 rows still fills the chip (one workgroup per row left 60 % of the CUs idle).
+__global__ __launch_bounds__(256) void k_dalpha(const float* __restrict__ datt, const float* __restrict__ sent,
+                                                const float* __restrict__ X, const float* __restrict__ rmask,
+                                                const int* __restrict__ slot, int M, int L, int R, int D, float* __restrict__ dalpha) {
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= M * (R + 1)) return;
+    const int row = item / (R + 1), j = item % (R + 1), lane = threadIdx.x & 63;
+    const long long sl = (long long)row * L + slot[row];
+    float s = 0.f;
+    if (j == 0 || rmask[sl * R + j - 1] != 0.f) {
+        const float* g = datt + (long long)row * D;
+        const float* src = (j == 0) ? sent + (long long)row * D : X + (sl * R + j - 1) * D;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+        int d = lane * 4;
+        for (; d + 768 < D; d += 1024) {
+            const float4 b0 = *reinterpret_cast<const float4*>(src + d), b1 = *reinterpret_cast<const float4*>(src + d + 256);
+            const float4 b2 = *reinterpret_cast<const float4*>(src + d + 512), b3 = *reinterpret_cast<const float4*>(src + d + 768);
+            const float4 a0 = *reinterpret_cast<const float4*>(g + d), a1 = *reinterpret_cast<const float4*>(g + d + 256);
+            const float4 a2 = *reinterpret_cast<const float4*>(g + d + 512), a3 = *reinterpret_cast<const float4*>(g + d + 768);
+            p0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
+            p1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+            p2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
+            p3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
+        }
+        for (; d < D; d += 256) {
+            const float4 a = *reinterpret_cast<const float4*>(g + d);
+            const float4 b = *reinterpret_cast<const float4*>(src + d);
+            p0 += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        s = wave_sum((p0 + p1) + (p2 + p3));
+    }
+    if (lane == 0) dalpha[item] = s;
+}
+
 // attention backward (:158-171, :187), one 256-thread workgroup per row.
 //   att = a0 * sent + sum_r a_r X_r ;  a = (softmax(z) * m) / sum(softmax(z) * m) ;  zsum = sum_r m_r z_r
 //   z_r = w_a . tanh(P_r + hA) ;  z_0 = w_s . tanh(sa + hA)
 // in : datt (M,D), dzsum (M), alpha (M,R+1), saved hA, sa, sent; P, X, rmask of the row's (image, slot)
 // out: dsent (M,D) = a0 * datt; dsa (M,A); dhA (M,A) += ; dP[(image,slot)] (R,A) += ; per-row partials of dw_a, dw_s
-__global__ __launch_bounds__(256) void k_attend_bwd(const float* __restrict__ datt, const float* __restrict__ dzsum,
+__global__ __launch_bounds__(256) void k_attend_bwd(const float* __restrict__ datt, const float* __restrict__ dalpha_in,
+                                                    const float* __restrict__ dzsum,
                                                     const float* __restrict__ alpha, const float* __restrict__ hA,
                                                     const float* __restrict__ sa, const float* __restrict__ sent,
                                                     const float* __restrict__ P, const float* __restrict__ X,
@@ -224,33 +260,8 @@ __global__ __launch_bounds__(256) void k_attend_bwd(const float* __restrict__ da
     const float* Xk = X + sl * R * D;
     const float* al = alpha + (long long)row * (R + 1);
     const float* mk = rmask + sl * R;
-    // dalpha_j = datt . regions_j   (wave w takes j = w, w+4, ...; masked rows have alpha = 0 and need no gradient).
-    // All eight 16-byte loads of a row are issued before the first use (independent accumulators).
-    for (int j = wave; j < R + 1; j += 4) {
-        float s = 0.f;
-        if (j == 0 || mk[j - 1] != 0.f) {
-            const float* src = (j == 0) ? sent + (long long)row * D : Xk + (long long)(j - 1) * D;
-            float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-            int d = lane * 4;
-            for (; d + 768 < D; d += 1024) {
-                const float4 b0 = *reinterpret_cast<const float4*>(src + d), b1 = *reinterpret_cast<const float4*>(src + d + 256);
-                const float4 b2 = *reinterpret_cast<const float4*>(src + d + 512), b3 = *reinterpret_cast<const float4*>(src + d + 768);
-                const float4 a0 = *reinterpret_cast<const float4*>(g + d), a1 = *reinterpret_cast<const float4*>(g + d + 256);
-                const float4 a2 = *reinterpret_cast<const float4*>(g + d + 512), a3 = *reinterpret_cast<const float4*>(g + d + 768);
-                p0 += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w;
-                p1 += a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
-                p2 += a2.x * b2.x + a2.y * b2.y + a2.z * b2.z + a2.w * b2.w;
-                p3 += a3.x * b3.x + a3.y * b3.y + a3.z * b3.z + a3.w * b3.w;
-            }
-            for (; d < D; d += 256) {
-                const float4 a = *reinterpret_cast<const float4*>(g + d);
-                const float4 b = *reinterpret_cast<const float4*>(src + d);
-                p0 += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-            }
-            s = wave_sum((p0 + p1) + (p2 + p3));
-        }
-        if (lane == 0) da[j] = s;
-    }
+    // dalpha comes from k_dalpha (one wave per (row, j))
+    for (int j = tid; j < R + 1; j += 256) da[j] = dalpha_in[(long long)row * (R + 1) + j];
     // dsent = alpha_0 * datt
     const float a0 = al[0];
     for (int d = tid * 4; d < D; d += 1024) {
