@@ -126,14 +126,26 @@ def train_bench(args):
                         torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed)).to(dev)))
     step = parallel.DataParallelStep(list(m.parameters()), opt, forward_fn=lambda d, cp, sq: m((d,), (cp, sq)),
                                      sample_fn=lambda d, ct: m.sample_rl(d, ct))
+    NS = 5                          # samples per image (BASELINE configs[4]); the reference has no such loop, the caller
+    rl_batches = []                 # repeats every image NS times
+    if not xe:
+        for det, reg, _, _ in batches:
+            rl_batches.append((det.repeat_interleave(NS, 0).contiguous(), reg.repeat_interleave(NS, 0).contiguous()))
 
-    def reward_fn(words):           # rewards are an INPUT of the RL step (CIDEr is out of scope): synthetic, on device
-        r = (words.sum(1) % 97).float() / 97.0
-        return r, torch.full_like(r, 0.5)
+    def score(words):               # rewards are an INPUT of the RL step (CIDEr is out of scope): synthetic, on device
+        return (words.sum(1) % 97).float() / 97.0
 
     def one_step(i):
         det, reg, caps, gts = batches[i & 1]
-        return step.xe_step(det, caps, reg, gts) if xe else step.scst_step(det, reg, reward_fn)
+        if xe:
+            return step.xe_step(det, caps, reg, gts)
+        with torch.no_grad():       # greedy baseline of train.py:127-138 (model.test), then NS samples per image
+            m.eval()
+            base_words, _ = m.test(det, reg)
+            m.train()
+        r_base = score(base_words).repeat_interleave(NS, 0)
+        det5, reg5 = rl_batches[i & 1]
+        return step.scst_step(det5, reg5, lambda words: (score(words), r_base))
 
     def barrier():
         if world > 1:
@@ -158,14 +170,14 @@ def train_bench(args):
     if rank == 0:
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         line = {
-            "metric": "XE-step samples/sec" if xe else "SCST-step samples/sec (1 sample/image, rewards given)",
+            "metric": "XE-step samples/sec" if xe else "SCST-step images/sec (5 samples/image + greedy baseline, rewards given)",
             "value": world * c["B"] * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("XE training step (forward + NLL losses + BPTT backward + Adam), batch 100/GPU, 20 slots x 36 regions x 2048-d, "
                                     "seq_len 20, vocab 10000 (BASELINE configs[3], fp32)") if xe else
-                                   ("SCST step (sample_rl + replayed forward + BPTT backward + Adam), batch 100/GPU, 10 slots x 36 x 2048 "
-                                    "(BASELINE configs[4], fp32)"),
+                                   ("SCST step: greedy baseline (100 images) + sample_rl on 500 rows (5 samples/image) + replayed forward + BPTT "
+                                    "backward + Adam, 10 slots x 36 x 2048 (BASELINE configs[4], fp32)"),
                        "batch_per_gpu": c["B"], "seq_len": c["T"], "parallelism": "dp%d, RCCL gradient all-reduce" % world},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
