@@ -34,7 +34,10 @@ struct Builder {
         GemmSeg& s = p.seg[p.nseg++]; s.A = A; s.lda = lda; s.a_idx = idx; s.W = W; s.ldw = ldw; s.K = K;
     }
     int finish() {
-        int ns = gemm_plan(a, slots, min_iters, tm >= 12 ? 128 : 64 * tm, tm >= 12 ? 128 : 64 * tn);
+        int bm = tm >= 12 ? 128 : 64 * tm, bn = tm >= 12 ? 128 : 64 * tn;
+        if (tm == 112) { bm = 64; bn = 128; }
+        if (tm == 121) { bm = 128; bn = 64; }
+        int ns = gemm_plan(a, slots, min_iters, bm, bn);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
         return ns;
     }
@@ -42,6 +45,8 @@ struct Builder {
     void launch(hipStream_t st) {
         dim3 g(((a.G + 7) / 8) * 8), b(256);
         if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
+        else if (tm == 112) hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 2, 2, 2>), g, b, 0, st, a);
+        else if (tm == 121) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 12) hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 2, 4, 2>), g, dim3(512), 0, st, a);
         else if (tm == 21) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1, 2, 4>), g, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 1>), g, b, 0, st, a);

@@ -78,7 +78,7 @@ struct vsr_handle {
     int gemm_slots = 1024;       // resident 64x64 GEMM workgroups to fill: 256 CUs x 4 (36.9 KB LDS each)
     int gemm_min_iters = 8;
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
-    int gemm_tile = 0;           // 0 = by M, 64 / 128 forced (VSR_GEMM_TILE)
+    int gemm_tile = 0;           // 0 = by M; VSR_GEMM_TILE=64 | 12864 | 128 forces 64x64 / 128x64 / 128x128
     Ctx c;
     // measurement
     bool profiling = false;
@@ -167,9 +167,11 @@ struct GemmBuilder {
     int finish(const vsr_handle* h) {
         int maxM = 0;
         for (int i = 0; i < a.nprob; ++i) maxM = std::max(maxM, a.p[i].M);
-        big = h->gemm_tile == 128 || (h->gemm_tile == 0 && maxM > 192);
-        // resident workgroups: 4 per CU at 36.9 KB LDS (64x64), 2 per CU at 73.7 KB (128x128)
-        return gemm_plan(a, big ? h->gemm_slots / 2 : h->gemm_slots, h->gemm_min_iters, big ? 128 : 64, big ? 128 : 64);
+        big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM > 192 ? 1 : 0);
+        // resident workgroups per CU: 4 at 36.9 KB LDS (64x64), 2 at 55.3 KB (128x64) or 73.7 KB (128x128).
+        // 128x64 is the default for tall problems: as fast as 128x128 in the GEMM itself (91.8 vs 93.7 TF/s) but its
+        // tiles are cut into ~3 stream-K pieces instead of ~5, so every consumer kernel reads 40 % fewer slab bytes.
+        return gemm_plan(a, big ? h->gemm_slots / 2 : h->gemm_slots, h->gemm_min_iters, big ? 128 : 64, big == 2 ? 128 : 64);
     }
     int launch(hipStream_t s, vsr_handle* h);
 };
@@ -178,7 +180,8 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     dim3 grid(((a.G + 7) / 8) * 8), block(256);
     const bool prof = h->profiling && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
-    if (big) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), grid, block, 0, s, a);
+    if (big == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), grid, block, 0, s, a);
+    else if (big == 1) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 1>), grid, block, 0, s, a);
     if (prof) {
         (void)hipEventRecord(h->ev[h->ev_used + 1], s);
