@@ -36,7 +36,8 @@ struct Builder {
     int finish() {
         int bm = tm >= 12 ? 128 : 64 * tm, bn = tm >= 12 ? 128 : 64 * tn;
         if (tm == 112) { bm = 64; bn = 128; }
-        if (tm == 121) { bm = 128; bn = 64; }
+        if (tm == 121 || tm == 221) { bm = 128; bn = 64; }
+        if (tm == 211) { bm = 64; bn = 64; }
         int ns = gemm_plan(a, slots, min_iters, bm, bn);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
         return ns;
@@ -45,6 +46,8 @@ struct Builder {
     void launch(hipStream_t st) {
         dim3 g(((a.G + 7) / 8) * 8), b(256);
         if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
+        else if (tm == 221) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<2, 1, 2, 2>), g, b, 0, st, a);
+        else if (tm == 211) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<1, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 112) hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 2, 2, 2>), g, b, 0, st, a);
         else if (tm == 121) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 12) hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 2, 4, 2>), g, dim3(512), 0, st, a);
@@ -261,6 +264,14 @@ int main(int argc, char** argv) {
         GemmProb& p0 = b.prob(M, V, C, V); Builder::seg(p0, h2, H, nullptr, Wout, H, H);
         int ns = b.finish(); double ms = time_it(b, 20);
         printf("S6  nslab %d G %5d  %8.1f us  %6.1f TF/s\n", ns, b.a.G, ms * 1e3, b.flops() / ms / 1e9); tot_ms += ms; tot_fl += b.flops();
+    }
+    if (getenv("GEMM_LONG")) {
+        const int KL = 16000, NL_ = 4096;
+        float* Al = dev_rand((size_t)M * KL, 31); float* Wl = dev_rand((size_t)NL_ * KL, 32);
+        Builder b(slots, min_iters, tm, tn);
+        GemmProb& p0 = b.prob(M, NL_, C, NL_); Builder::seg(p0, Al, KL, nullptr, Wl, KL, KL);
+        int ns = b.finish(); double ms = time_it(b, 10);
+        printf("LONG K=%d N=%d nslab %d G %5d  %8.1f us  %6.1f TF/s\n", KL, NL_, ns, b.a.G, ms * 1e3, b.flops() / ms / 1e9);
     }
     printf("step GEMMs M=%d slots %d min_iters %d tile %dx%d: %.1f us, %.1f TF/s\n", M, slots, min_iters, 64 * tm, 64 * tn, tot_ms * 1e3, tot_fl / tot_ms / 1e9);
     return 0;

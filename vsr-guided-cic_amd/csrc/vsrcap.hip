@@ -78,6 +78,7 @@ struct vsr_handle {
     int gemm_slots = 1024;       // resident 64x64 GEMM workgroups to fill: 256 CUs x 4 (36.9 KB LDS each)
     int gemm_min_iters = 8;
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
+    int gemm_dma = 0;            // VSR_GEMM_DMA=1: LDS-DMA 3-stage variant for the 128x64 tile (measured equal: DESIGN.md)
     int gemm_tile = 0;           // 0 = by M; VSR_GEMM_TILE=64 | 12864 | 128 forces 64x64 / 128x64 / 128x128
     Ctx c;
     // measurement
@@ -167,8 +168,9 @@ struct GemmBuilder {
     int finish(const vsr_handle* h) {
         int maxM = 0;
         for (int i = 0; i < a.nprob; ++i) maxM = std::max(maxM, a.p[i].M);
-        big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM > 192 ? 1 : 0);
+        big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM >= 1024 ? 2 : maxM > 192 ? 1 : 0);
         // resident workgroups per CU: 4 at 36.9 KB LDS (64x64), 2 at 55.3 KB (128x64) or 73.7 KB (128x128).
+        // 128x128 for M >= 1024 (weight-gradient GEMMs: one tile per workgroup, 130 TF/s at long K);
         // 128x64 is the default for tall problems: as fast as 128x128 in the GEMM itself (91.8 vs 93.7 TF/s) but its
         // tiles are cut into ~3 stream-K pieces instead of ~5, so every consumer kernel reads 40 % fewer slab bytes.
         return gemm_plan(a, big ? h->gemm_slots / 2 : h->gemm_slots, h->gemm_min_iters, big ? 128 : 64, big == 2 ? 128 : 64);
@@ -181,6 +183,7 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     const bool prof = h->profiling && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
     if (big == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), grid, block, 0, s, a);
+    else if (big == 1 && h->gemm_dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<2, 1>), grid, block, 0, s, a);
     else if (big == 1) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 1>), grid, block, 0, s, a);
     if (prof) {
@@ -217,6 +220,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
         h->gemm_slots = prop.multiProcessorCount * 4;
     if (const char* e = getenv("VSR_GEMM_SLOTS")) h->gemm_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e);
+    if (const char* e = getenv("VSR_GEMM_DMA")) h->gemm_dma = atoi(e);
     if (const char* e = getenv("VSR_GEMM_MIN_ITERS")) h->gemm_min_iters = std::max(1, atoi(e));
     *out = h;
     return 0;
