@@ -32,8 +32,6 @@ struct TrainCtx {
     size_t tpad_bytes = 0;
 };
 
-static TrainCtx g_tc_dummy;
-
 static inline size_t up4(size_t x) { return (x + 3) & ~size_t(3); }
 
 static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
