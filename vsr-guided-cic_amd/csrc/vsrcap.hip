@@ -522,10 +522,16 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
                    io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row
         const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;          // combined logits row staged in LDS (<= 96 KB)
         const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
-        if (io.K <= 1) hipLaunchKernelGGL((k_vocab<1>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS);
-        else if (io.K <= 2) hipLaunchKernelGGL((k_vocab<2>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS);
-        else if (io.K <= 4) hipLaunchKernelGGL((k_vocab<4>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS);
-        else hipLaunchKernelGGL((k_vocab<8>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS);
+        switch (io.K) {        // K = beam exactly: fewer insertion steps and merge rounds than rounding up to a power of two
+            case 1: hipLaunchKernelGGL((k_vocab<1>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
+            case 2: hipLaunchKernelGGL((k_vocab<2>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
+            case 3: hipLaunchKernelGGL((k_vocab<3>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
+            case 4: hipLaunchKernelGGL((k_vocab<4>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
+            case 5: hipLaunchKernelGGL((k_vocab<5>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
+            case 6: hipLaunchKernelGGL((k_vocab<6>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
+            case 7: hipLaunchKernelGGL((k_vocab<7>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
+            default: hipLaunchKernelGGL((k_vocab<8>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
+        }
 #undef VOCAB_ARGS
     }
     LAUNCHCHK();
@@ -604,7 +610,7 @@ extern "C" int vsr_beam(vsr_handle* h, int32_t beam, int32_t out_size, int64_t e
     if (!words || !gates) return fail("vsr_beam: null output");
     hipStream_t s = (hipStream_t)stream;
     const int B = c.B, T = h->d.seq_len;
-    const int K = beam <= 1 ? 1 : beam <= 2 ? 2 : beam <= 4 ? 4 : 8;
+    const int K = beam;
     if (zero_state(h, B, s)) return 1;
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
@@ -619,10 +625,16 @@ extern "C" int vsr_beam(vsr_handle* h, int32_t beam, int32_t out_size, int64_t e
 #define SEL_ARGS t, cb, beam, c.L, eos_word, eos_gate, c.top_v, c.top_i, c.lg, c.slot[cur], c.word[cur], c.gate[cur], c.seq[cur], \
                  c.seq[cur ^ 1], c.mask[cur], c.mask[cur ^ 1], c.word[cur ^ 1], c.gate[cur ^ 1], c.slot[cur ^ 1], c.parent,       \
                  c.hist_parent, c.hist_word, c.hist_gate, c.hist_lpw, c.hist_lpg, B
-        if (K == 1) hipLaunchKernelGGL((k_select_beam<1>), dim3(B), dim3(64), 0, s, SEL_ARGS);
-        else if (K == 2) hipLaunchKernelGGL((k_select_beam<2>), dim3(B), dim3(64), 0, s, SEL_ARGS);
-        else if (K == 4) hipLaunchKernelGGL((k_select_beam<4>), dim3(B), dim3(64), 0, s, SEL_ARGS);
-        else hipLaunchKernelGGL((k_select_beam<8>), dim3(B), dim3(64), 0, s, SEL_ARGS);
+        switch (K) {
+            case 1: hipLaunchKernelGGL((k_select_beam<1>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
+            case 2: hipLaunchKernelGGL((k_select_beam<2>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
+            case 3: hipLaunchKernelGGL((k_select_beam<3>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
+            case 4: hipLaunchKernelGGL((k_select_beam<4>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
+            case 5: hipLaunchKernelGGL((k_select_beam<5>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
+            case 6: hipLaunchKernelGGL((k_select_beam<6>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
+            case 7: hipLaunchKernelGGL((k_select_beam<7>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
+            default: hipLaunchKernelGGL((k_select_beam<8>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
+        }
 #undef SEL_ARGS
         LAUNCHCHK();
     }
