@@ -201,23 +201,38 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     for (int a = tid; a < A; a += 256) hA_s[a] = hA[(long long)row * A + a];
     __syncthreads();
 
-    // scores: wave w takes regions w, w+4, ...; wave 3 also takes the sentinel at the end
+    // scores: wave w takes rows w, w+4, ... of [regions ; sentinel]; four rows per pass so that their projection
+    // loads are all in flight before the first tanh (one L2 round trip per pass instead of one per row)
     const float* Pk = P + sl * R * A;
-    for (int r = wave; r < R + 1; r += 4) {
-        const float* src = (r < R) ? Pk + (long long)r * A : sa + (long long)row * A;
-        const float* wv = (r < R) ? w_a : w_s;
-        float s = 0.f;
+    for (int r0 = wave; r0 < R + 1; r0 += 16) {
+        float sc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int a = lane * 4; a < A; a += 256) {
-            const float4 p = *reinterpret_cast<const float4*>(src + a);
+            float4 p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 4 * q;
+                const float* src = (r < R) ? Pk + (long long)r * A : sa + (long long)row * A;
+                p[q] = (r < R + 1) ? *reinterpret_cast<const float4*>(src + a) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             const float4 h = *reinterpret_cast<const float4*>(hA_s + a);
-            const float4 w = *reinterpret_cast<const float4*>(wv + a);
-            s += w.x * tanhf(p.x + h.x);
-            s += w.y * tanhf(p.y + h.y);
-            s += w.z * tanhf(p.z + h.z);
-            s += w.w * tanhf(p.w + h.w);
+            const float4 wa = *reinterpret_cast<const float4*>(w_a + a);
+            const float4 ws = *reinterpret_cast<const float4*>(w_s + a);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + 4 * q;
+                const float4 w = (r < R) ? wa : ws;
+                sc[q] += w.x * tanhf(p[q].x + h.x);
+                sc[q] += w.y * tanhf(p[q].y + h.y);
+                sc[q] += w.z * tanhf(p[q].z + h.z);
+                sc[q] += w.w * tanhf(p[q].w + h.w);
+            }
         }
-        s = wave_sum(s);
-        if (lane == 0) z_s[(r < R) ? r + 1 : 0] = s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + 4 * q;
+            const float v = wave_sum(sc[q]);
+            if (lane == 0 && r < R + 1) z_s[(r < R) ? r + 1 : 0] = v;
+        }
     }
     // sentinel row-sum for its mask
     const float* srow = sent + (long long)row * D;
