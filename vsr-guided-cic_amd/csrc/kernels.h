@@ -118,11 +118,14 @@ __global__ void k_i32_to_i64(const int* src, int64_t* dst, int n) {
 __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ vproj,
                         int rpi, const int* __restrict__ parent, const float* __restrict__ c1_old, int M, int H,
                         float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre,
-                        const float* __restrict__ xproj, const int* __restrict__ word, int nblk) {
+                        const float* __restrict__ xproj, const int* __restrict__ word, int nblk, int pre_by_parent) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
-    const long long base = (long long)row * 6 * H + j;
+    const int prow = parent ? parent[row] : row;
+    // pre_by_parent: the sums were produced one step early over the PRE-selection rows (merged with the previous
+    // step's vocabulary GEMM), so this row reads the sums of the hypothesis it descends from
+    const long long base = (long long)(pre_by_parent ? prow : row) * 6 * H + j;
     const float* vp = vproj + (long long)(row / rpi) * 6 * H + j;
     const float* xp = xproj ? xproj + (long long)word[row] * 6 * H + j : nullptr;
     float q[6];
@@ -134,7 +137,6 @@ __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long str
         if (xp) s += xp[(long long)g * H];
         q[g] = s + vp[(long long)g * H];
     }
-    const int prow = parent ? parent[row] : row;
     const float c_old = c1_old[(long long)prow * H + j];
     const float c = sigmoidf_(q[1]) * c_old + sigmoidf_(q[0]) * tanhf(q[2]);
     const float tc = tanhf(c);

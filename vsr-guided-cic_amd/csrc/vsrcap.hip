@@ -60,6 +60,9 @@ struct Ctx {
     int64_t* tmp_i64;
     float* scratch;
     size_t scratch_floats = 0;
+    float* pre1 = nullptr;       // LSTM1/gate sums of the NEXT step, produced early (merged with the vocabulary GEMM)
+    int pre1_ns = 0, pre1_nblk = 0;
+    long long pre1_stride = 0;
 };
 
 struct TrainCtx;
@@ -146,6 +149,7 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     size_t stage = std::max(M * widest, B * 6 * H);
     c.scratch_floats = std::max(stage * 8, rows * A * 8);       // att_va slabs of prepare()
     c.scratch = b.take<float>(c.scratch_floats);
+    c.pre1 = b.take<float>(M * 6 * H * 8);
     return (b.off + 255) & ~size_t(255);
 }
 
@@ -415,6 +419,8 @@ struct StepIO {
     const float* verbs; int gt;
     float* lg_out; long long lg_stride;
     float* alpha_out;
+    bool s1_from_prev = false;   // this step's LSTM1 sums are already in c.pre1 (computed over the parent rows)
+    bool s1_for_next = false;    // compute the next step's LSTM1 sums together with this step's vocabulary GEMM
 };
 
 static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
@@ -432,7 +438,10 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     float *h1n = sn[0], *c1n = sn[1], *h2n = sn[2], *c2n = sn[3];
 
     // ---- S1
-    {
+    if (io.s1_from_prev) {
+        hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.pre1, c.pre1_ns, c.pre1_stride, c.vproj, io.rpi,
+                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, c.pre1_nblk, 1);
+    } else {
         const bool xc = h->xproj != nullptr;            // embedding part comes from the decode cache
         GemmBuilder g;
         const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
@@ -457,7 +466,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
             if (g.launch(s, h)) return fail("S1 gemm launch failed");
         }
         hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj, io.rpi,
-                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, nblk);
+                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, nblk, 0);
     }
     // ---- S2
     {
@@ -514,9 +523,27 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         GemmBuilder g;
         GemmProb& p0 = g.prob(M, V, c.scratch, V);
         GemmBuilder::seg(p0, h2n, H, nullptr, w.out_fc_weight, H, H);
+        int nblk = 0;
+        if (io.s1_for_next) {
+            // LSTM1 / gate sums of step t+1 over THIS step's rows: they depend on (h2, h1) only (the word enters through the
+            // decode cache, the beam re-indexing through k_lstm1's parent gather), so they ride in the same launch as the
+            // vocabulary projection: 3 GEMM launches per timestep instead of 4, and a longer stream-K range per workgroup.
+            const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
+            const float* Whh[3] = {w.lstm1_weight_hh, w.W1_hs_weight, nullptr};
+            const int Nn[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
+            for (int i = 0; i < 3; ++i) {
+                if (!d.h2_first_lstm && !Whh[i]) continue;
+                GemmProb& p = g.prob(M, Nn[i], c.pre1 + off[i], 6 * H);
+                if (d.h2_first_lstm) GemmBuilder::seg(p, h2n, H, nullptr, Wih[i], in1, H);
+                if (Whh[i]) GemmBuilder::seg(p, h1n, H, nullptr, Whh[i], H, H);
+                nblk = i == 0 ? 4 : i == 1 ? 5 : 6;
+            }
+        }
         const int ns = g.finish(h);
         const long long stride = (long long)M * V;
         g.a.p[0].slab_stride = stride;
+        for (int i = 1; i < g.a.nprob; ++i) g.a.p[i].slab_stride = (long long)M * 6 * H;
+        c.pre1_ns = ns; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
         if (g.launch(s, h)) return fail("S6 gemm launch failed");
 #define VOCAB_ARGS c.scratch, ns, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
                    io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row
@@ -576,6 +603,8 @@ static int decode_simple(vsr_handle* h, int vmode, uint64_t seed, const int64_t*
         io.vmode = vmode; io.K = 1; io.full_out = nullptr; io.full_stride = 0;
         io.forced = (vmode == VM_FORCED) ? c.forced_w32 + (size_t)t * B : nullptr;
         io.seed = seed; io.verbs = verbs; io.gt = gt; io.lg_out = c.lg; io.lg_stride = 2; io.alpha_out = nullptr;
+        io.s1_from_prev = t > 0 && h->xproj != nullptr;
+        io.s1_for_next = t + 1 < T && h->xproj != nullptr;
         if (run_step(h, io, s)) return 1;
         hipLaunchKernelGGL(k_select_simple, dim3(cdiv(B, 256)), dim3(256), 0, s, vmode, c.top_v, c.top_i, c.lg,
                            (vmode == VM_FORCED) ? c.forced_g32 + (size_t)t * B : nullptr, seed, (uint32_t)t, c.slot[cur], c.L, B, T,
@@ -621,6 +650,8 @@ extern "C" int vsr_beam(vsr_handle* h, int32_t beam, int32_t out_size, int64_t e
         io.parent = t == 0 ? nullptr : c.parent; io.word_prev = c.word[cur]; io.slot = c.slot[cur]; io.fixed_slot = 0;
         io.vmode = VM_TOPK; io.K = K; io.forced = nullptr; io.seed = 0; io.verbs = verbs; io.gt = gt;
         io.lg_out = c.lg; io.lg_stride = 2; io.alpha_out = nullptr;
+        io.s1_from_prev = t > 0 && h->xproj != nullptr;
+        io.s1_for_next = t + 1 < T && h->xproj != nullptr;
         if (run_step(h, io, s)) return 1;
 #define SEL_ARGS t, cb, beam, c.L, eos_word, eos_gate, c.top_v, c.top_i, c.lg, c.slot[cur], c.word[cur], c.gate[cur], c.seq[cur], \
                  c.seq[cur ^ 1], c.mask[cur], c.mask[cur ^ 1], c.word[cur ^ 1], c.gate[cur ^ 1], c.slot[cur ^ 1], c.parent,       \
