@@ -11,7 +11,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name says host_; tensors are dense row-major fp32 /
  *     int64 / int32 exactly as the reference lays them out (weights: [out, in]).
- *   - all work is enqueued on the caller's hipStream_t (passed as void*); no call synchronises the host.
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*); no call synchronises the host, with ONE
+ *     exception: vsr_prepare() reads back a single integer (the number of non-padding region rows, which sizes the
+ *     hoisted att_va GEMM) and therefore waits for the stream once.
  *   - the library allocates nothing on the launch path: the caller provides one workspace of
  *     vsr_workspace_bytes() bytes (16-byte aligned) that must stay untouched between vsr_prepare() and
  *     the decode / forward calls that use it.

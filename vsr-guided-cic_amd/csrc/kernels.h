@@ -71,6 +71,40 @@ __global__ __launch_bounds__(256) void k_rowmask(const float* __restrict__ X, lo
     if (lane == 0) mask[row] = (s != 0.f) ? 1.f : 0.f;
 }
 
+// list of the non-padding region rows (ascending) and their count: one 1024-thread block, chunked exclusive scan.
+// att_va(0) = 0 (no bias), so the hoisted region projection only has to run over these rows.
+__global__ __launch_bounds__(1024) void k_compact_rows(const float* __restrict__ mask, int rows, int* __restrict__ vlist, int* __restrict__ count) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (rows + 1023) / 1024;
+    const int r0 = tid * per, r1 = min(rows, r0 + per);
+    int n = 0;
+    for (int r = r0; r < r1; ++r) n += mask[r] != 0.f;
+    part[tid] = n;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {           // Hillis-Steele inclusive scan
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int pos = part[tid] - n;
+    for (int r = r0; r < r1; ++r)
+        if (mask[r] != 0.f) vlist[pos++] = r;
+    if (tid == 1023) *count = part[1023];
+}
+
+// P[vlist[m]] = sum of the slabs' row m   (scatter of the compact projection back to the dense row index)
+__global__ void k_slab_reduce_scatter(const float* __restrict__ slabs, int nslab, long long stride, int rows, int A,
+                                      const int* __restrict__ vlist, float* __restrict__ P) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * A) return;
+    const int m = (int)(i / A), a = (int)(i % A);
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
+    P[(long long)vlist[m] * A + a] = s;
+}
+
 // hoisted image part of the LSTM1 / gate pre-activations: sum the split-K slabs and fold in all biases.
 // n in [0,4H): b_ih + b_hh of lstm_cell_1;  [4H,5H): W1_is.bias + W1_hs.bias;  [5H,6H): W1_ig.bias + W1_hg.bias
 __global__ void k_vproj_finish(const float* __restrict__ slabs, int nsplit, long long stride, int B, int H,
@@ -206,6 +240,7 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     // scores: wave w takes rows w, w+4, ... of [regions ; sentinel]; four rows per pass so that their projection
     // loads are all in flight before the first tanh (one L2 round trip per pass instead of one per row)
     const float* Pk = P + sl * R * A;
+    const float* mk_row = rmask + sl * R;
     for (int r0 = wave; r0 < R + 1; r0 += 16) {
         float sc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int a = lane * 4; a < A; a += 256) {
@@ -214,7 +249,9 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
             for (int q = 0; q < 4; ++q) {
                 const int r = r0 + 4 * q;
                 const float* src = (r < R) ? Pk + (long long)r * A : sa + (long long)row * A;
-                p[q] = (r < R + 1) ? *reinterpret_cast<const float4*>(src + a) : make_float4(0.f, 0.f, 0.f, 0.f);
+                // padding rows were never projected (att_va(0) = 0): their P entry is not defined, use the exact zero
+                const bool live = r < R + 1 && (r >= R || mk_row[r] != 0.f);
+                p[q] = live ? *reinterpret_cast<const float4*>(src + a) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             const float4 h = *reinterpret_cast<const float4*>(hA_s + a);
             const float4 wa = *reinterpret_cast<const float4*>(w_a + a);

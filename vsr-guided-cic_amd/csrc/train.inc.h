@@ -314,7 +314,8 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     HIPCHK(hipMemsetAsync(t.dh2_c, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dc1_c[0], 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dc2_c[0], 0, BH * sizeof(float), s));
-    if (TBp != TB || Bp != B || RLp != RL) HIPCHK(hipMemsetAsync(t.tpad_begin, 0, t.tpad_bytes, s));
+    const int NV = c.nvalid, NVp = (int)up4((size_t)NV);     // non-padding region rows: the only ones att_va saw
+    if (TBp != TB || Bp != B || NVp != NV) HIPCHK(hipMemsetAsync(t.tpad_begin, 0, t.tpad_bytes, s));
 
     // ---- phase 0: dlogits (t,b) and the vocabulary part of dh2 for every step
     hipLaunchKernelGGL(k_dlogits_tb, dim3(TB), dim3(256), 0, s, t.logp_w, grad_logp_words, B, T, V, Vp, t.dlogits);
@@ -444,7 +445,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     transpose(s, t.g_ts, H, TB, H, t.tX_gt, TBp);
     transpose(s, h2cur, H, TB, H, t.tX_h2, TBp);
     transpose(s, c.vbar, D, B, D, t.tX_vbar, Bp);
-    transpose(s, c.regions, D, RL, D, t.tX_reg, RLp);
+    if (NV > 0) hipLaunchKernelGGL(k_transpose_gather, dim3(cdiv(D, 32), cdiv(NV, 32)), dim3(256), 0, s, c.regions, (long long)D, c.vlist, NV, D, t.tX_reg, (long long)NVp);
     transpose(s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp);
     transpose(s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp);
     transpose(s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp);
@@ -452,7 +453,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     transpose(s, t.dsent_all, D, TB, D, t.tY_dsent, TBp);
     transpose(s, t.dsa_all, A, TB, A, t.tY_dsa, TBp);
     transpose(s, t.dga_all, A, TB, A, t.tY_dga, TBp);
-    transpose(s, t.dP, A, RL, A, t.tY_dP, RLp);
+    if (NV > 0) hipLaunchKernelGGL(k_transpose_gather, dim3(cdiv(A, 32), cdiv(NV, 32)), dim3(256), 0, s, t.dP, (long long)A, c.vlist, NV, A, t.tY_dP, (long long)NVp);
     hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 6 * H, 256)), dim3(256), 0, s, t.dpre1, T, (long long)B * 6 * H, t.dpre1sum);
     transpose(s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
     LAUNCHCHK();
@@ -497,8 +498,12 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         colsum(t, s, t.dpre1 + 5 * H, (long long)6 * H, TB, H, G[g_big]);
         HIPCHK(hipMemcpyAsync(G[g_bhg], G[g_big], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
-    // att_va: dP^T (A, RL) x regions^T (D, RL)
-    if (gemm_to1(h, t, s, A, D, RLp, t.tY_dP, RLp, t.tX_reg, RLp, G[g_Wva], D)) return 1;
+    // att_va: dP^T (A, NV) x regions^T (D, NV) over the non-padding rows
+    if (NV > 0) {
+        if (gemm_to1(h, t, s, A, D, NVp, t.tY_dP, NVp, t.tX_reg, NVp, G[g_Wva], D)) return 1;
+    } else {
+        HIPCHK(hipMemsetAsync(G[g_Wva], 0, (size_t)A * D * sizeof(float), s));
+    }
     // the three score vectors
     colsum(t, s, t.dwa_rows, (long long)A, TB, A, G[g_wa]);
     colsum(t, s, t.dws_rows, (long long)A, TB, A, G[g_ws]);

@@ -24,6 +24,19 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in,
         if (c0 + i < C && r0 + tx < R) out[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
 }
 
+// out (C, n) = rows list[0..n) of in (., C), transposed: out[c][j] = in[list[j]][c]
+__global__ __launch_bounds__(256) void k_transpose_gather(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int n,
+                                                          int C, float* __restrict__ out, long long ld_out) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < n && c0 + tx < C) t[i][tx] = in[(long long)list[r0 + i] * ld_in + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < n) out[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
+}
+
 // dst (rows, w) window with leading dimension ldd  =  sum of nslab compact (rows, w) slabs
 __global__ void k_slab_reduce_2d(const float* __restrict__ slabs, int nslab, long long stride, int rows, int w,
                                  float* __restrict__ dst, long long ldd) {

@@ -49,6 +49,8 @@ struct Ctx {
     const float* det = nullptr;
     const float* regions = nullptr;
     float *vbar, *vproj, *vproj2, *P, *rmask;
+    int *vlist, *nvalid_dev;     // non-padding region rows (ascending) and their number
+    int nvalid = 0;
     float* st[2][4];   // h1, c1, h2, c2 double-buffered
     int *slot[2], *word[2], *gate[2], *parent;
     float *s_t, *gpre, *g_t, *hA, *sa, *sent, *att, *zsum, *lg, *top_v;
@@ -114,6 +116,8 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     c.vproj2 = b.take<float>(B * 4 * H);
     c.P = b.take<float>(rows * A);
     c.rmask = b.take<float>(rows);
+    c.vlist = b.take<int>(rows);
+    c.nvalid_dev = b.take<int>(4);
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 4; ++j) c.st[i][j] = b.take<float>(M * H);
     for (int i = 0; i < 2; ++i) {
@@ -389,16 +393,20 @@ extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R
         hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.vproj2);
         LAUNCHCHK();
     }
-    // att_va over every region row of every slot: (B*L*R, D) x (A, D)^T -> P
-    {
+    // att_va over the NON-PADDING region rows only (att_va(0) = 0): compact row list, gathered GEMM, scatter back.
+    // The row count has to reach the host to size the launch: the one place where this library waits for the stream.
+    hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, s, c.rmask, (int)rows, c.vlist, c.nvalid_dev);
+    HIPCHK(hipMemcpyAsync(&c.nvalid, c.nvalid_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (c.nvalid > 0) {
         GemmBuilder g;
-        GemmProb& p0 = g.prob((int)rows, A, c.scratch, A);
-        GemmBuilder::seg(p0, regions, D, nullptr, w.att_va_weight, D, D);
+        GemmProb& p0 = g.prob(c.nvalid, A, c.scratch, A);
+        GemmBuilder::seg(p0, regions, D, c.vlist, w.att_va_weight, D, D);
         const int ns = g.finish(h);
-        const long long stride = rows * A;
+        const long long stride = (long long)c.nvalid * A;
         g.a.p[0].slab_stride = stride;
         if (g.launch(s, h)) return fail("att_va gemm launch failed");
-        hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.P);
+        hipLaunchKernelGGL(k_slab_reduce_scatter, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.nvalid, A, c.vlist, c.P);
         LAUNCHCHK();
     }
     h->prepared = true;
