@@ -321,18 +321,20 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
         const float4 s = *reinterpret_cast<const float4*>(srow + d);
         float4 acc = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
         int r = 0;
-        for (; r + 4 <= R; r += 4) {
-            const float al0 = z_s[r + 1], al1 = z_s[r + 2], al2 = z_s[r + 3], al3 = z_s[r + 4];
-            if (al0 == 0.f && al1 == 0.f && al2 == 0.f && al3 == 0.f) continue;
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 x0 = al0 != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + 0) * D + d) : z4;
-            const float4 x1 = al1 != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + 1) * D + d) : z4;
-            const float4 x2 = al2 != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + 2) * D + d) : z4;
-            const float4 x3 = al3 != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + 3) * D + d) : z4;
-            acc.x += al0 * x0.x; acc.y += al0 * x0.y; acc.z += al0 * x0.z; acc.w += al0 * x0.w;
-            acc.x += al1 * x1.x; acc.y += al1 * x1.y; acc.z += al1 * x1.z; acc.w += al1 * x1.w;
-            acc.x += al2 * x2.x; acc.y += al2 * x2.y; acc.z += al2 * x2.z; acc.w += al2 * x2.w;
-            acc.x += al3 * x3.x; acc.y += al3 * x3.y; acc.z += al3 * x3.z; acc.w += al3 * x3.w;
+        for (; r + 8 <= R; r += 8) {
+            float al[8];
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { al[q] = z_s[r + 1 + q]; any |= al[q] != 0.f; }
+            if (!any) continue;
+            float4 x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                x[q] = al[q] != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + q) * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                acc.x += al[q] * x[q].x; acc.y += al[q] * x[q].y; acc.z += al[q] * x[q].z; acc.w += al[q] * x[q].w;
+            }
         }
         for (; r < R; ++r) {
             const float al = z_s[r + 1];
