@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
+#include "../vsr-guided-cic_amd/csrc/gemm_bf16x3.h"
 
 using namespace vsr;
 
@@ -36,7 +37,8 @@ struct Builder {
     int finish() {
         int bm = tm >= 12 ? 128 : 64 * tm, bn = tm >= 12 ? 128 : 64 * tn;
         if (tm == 112) { bm = 64; bn = 128; }
-        if (tm == 121 || tm == 221) { bm = 128; bn = 64; }
+        if (tm == 121 || tm == 221 || tm == 321) { bm = 128; bn = 64; }
+        if (tm == 322) { bm = 128; bn = 128; }
         if (tm == 211) { bm = 64; bn = 64; }
         int ns = gemm_plan(a, slots, min_iters, bm, bn);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
@@ -46,6 +48,8 @@ struct Builder {
     void launch(hipStream_t st) {
         dim3 g(((a.G + 7) / 8) * 8), b(256);
         if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
+        else if (tm == 322) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2>), g, b, 0, st, a);
+        else if (tm == 321) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 221) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<2, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 211) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<1, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 112) hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 2, 2, 2>), g, b, 0, st, a);
@@ -216,6 +220,26 @@ int main(int argc, char** argv) {
         }
         printf("correctness (G %d, nslab %d): max |err| = %.3g %s\n", b.a.G, ns, maxerr, maxerr < 1e-4 ? "OK" : "FAIL");
         if (maxerr >= 1e-4 && !GEMM_ABLATE && !getenv("GEMM_NOCHECK")) return 1;
+    }
+
+    // ---- accuracy on a decoder-like product (M=64, N=256, K=1000) against fp64: this variant vs the fp32-MFMA kernel
+    {
+        const int m = 64, n = 256, kk = 1000;
+        float* A1 = dev_rand((size_t)m * kk, 41); float* W = dev_rand((size_t)n * kk, 42);
+        float* Cx; CK(hipMalloc(&Cx, (size_t)8 * m * n * sizeof(float)));
+        std::vector<float> hA((size_t)m * kk), hW((size_t)n * kk);
+        CK(hipMemcpy(hA.data(), A1, hA.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hW.data(), W, hW.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<double> ref((size_t)m * n);
+        for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < kk; ++k) s += (double)hA[(size_t)i * kk + k] * hW[(size_t)j * kk + k]; ref[(size_t)i * n + j] = s; }
+        for (int variant = 0; variant < 2; ++variant) {
+            Builder b(slots, min_iters, variant ? tm : 1, variant ? tn : 1);
+            GemmProb& p = b.prob(m, n, Cx, n); Builder::seg(p, A1, kk, nullptr, W, kk, kk);
+            int ns = b.finish(); b.launch(0); CK(hipDeviceSynchronize());
+            std::vector<float> hC((size_t)ns * m * n); CK(hipMemcpy(hC.data(), Cx, hC.size() * 4, hipMemcpyDeviceToHost));
+            double maxe = 0, sume = 0;
+            for (size_t i = 0; i < (size_t)m * n; ++i) { double g = 0; for (int q = 0; q < ns; ++q) g += hC[(size_t)q * m * n + i]; double e = fabs(g - ref[i]); maxe = fmax(maxe, e); sume += e * e; }
+            printf("accuracy K=1000 (%s): max |err| %.3e rms %.3e (|C| ~ %.2f)\n", variant ? "this variant" : "fp32 MFMA 64x64", maxe, sqrt(sume / (m * n)), 2.6);
+        }
     }
 
     // ---- timing on the decoder shapes
