@@ -40,6 +40,9 @@ struct Builder {
         if (tm == 121 || tm == 221 || tm == 321) { bm = 128; bn = 64; }
         if (tm == 322) { bm = 128; bn = 128; }
         if (tm == 211) { bm = 64; bn = 64; }
+        if (tm == 2242) { bm = 256; bn = 128; }
+        if (tm == 2142) { bm = 256; bn = 64; }
+        if (tm == 2224) { bm = 128; bn = 256; }
         int ns = gemm_plan(a, slots, min_iters, bm, bn);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
         return ns;
@@ -53,6 +56,9 @@ struct Builder {
         else if (tm == 221) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<2, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 211) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<1, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 112) hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 2, 2, 2>), g, b, 0, st, a);
+        else if (tm == 2242) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2, 4, 2>), g, dim3(512), 0, st, a);
+        else if (tm == 2142) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1, 4, 2>), g, dim3(512), 0, st, a);
+        else if (tm == 2224) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2, 2, 4>), g, dim3(512), 0, st, a);
         else if (tm == 121) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 12) hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 2, 4, 2>), g, dim3(512), 0, st, a);
         else if (tm == 21) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1, 2, 4>), g, dim3(512), 0, st, a);
@@ -74,6 +80,24 @@ static double time_it(Builder& b, int reps) {
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+#if defined(GEMM_PHASES)
+    {
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) CK(hipMalloc(&dbg, 4096 * 8 * 8));
+        CK(hipMemset(dbg, 0, 4096 * 8 * 8));
+        b.a.dbg = dbg;
+        b.launch(0);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h(8 * b.a.G);
+        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        double v[5] = {0};
+        for (int i = 0; i < b.a.G; ++i) for (int q = 0; q < 5; ++q) v[q] += h[8 * i + q];
+        const double n = v[4] > 0 ? v[4] : 1;
+        printf("    per k-step (s_memtime ticks, wave 0): issue loads %.0f | multiply %.0f | wait loads + ds_write %.0f | barrier %.0f | total %.0f\n",
+               v[0] / n, v[1] / n, v[2] / n, v[3] / n, (v[0] + v[1] + v[2] + v[3]) / n);
+        b.a.dbg = nullptr;
+    }
+#endif
 #if defined(GEMM_STAMP)
     {
         std::vector<unsigned long long> h(4 * b.a.G);
@@ -189,7 +213,9 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 500;
     const int slots = argc > 2 ? atoi(argv[2]) : 1024, min_iters = argc > 3 ? atoi(argv[3]) : 8;
     const int tm = argc > 4 ? atoi(argv[4]) : 1, tn = argc > 5 ? atoi(argv[5]) : 1;
-    const int H = 1000, E = 1000, D = 2048, A = 512, V = 10000, in1 = 4048, in2 = 3048;
+    // GEMM_ALIGNED=1: hidden sizes rounded to 1024 so that every row stride is a multiple of 128 B (cache-line aligned rows)
+    const bool aligned = getenv("GEMM_ALIGNED") != nullptr;
+    const int H = aligned ? 1024 : 1000, E = H, D = 2048, A = 512, V = 10000, in1 = H + D + E, in2 = H + D;
 
     // ---- correctness on a ragged problem: gather index, 3 segments with K tails, split-K, column window
     {

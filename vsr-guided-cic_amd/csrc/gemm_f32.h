@@ -273,6 +273,9 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
     store_tile(0);
     __syncthreads();
     int cur = 0;
+#if defined(GEMM_PHASES)
+    unsigned long long phs[5] = {0, 0, 0, 0, 0};
+#endif
     // Outer loop: one tile piece; inner loop: its k iterations.  The accumulator is only ever touched by MFMAs
     // inside the inner loop, so it stays in the accumulator registers (a VALU read/zero of it inside the k loop
     // made hipcc shuttle all 16 registers through v_accvgpr_read/write and drain the MFMA pipe every iteration).
@@ -287,7 +290,13 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
         const int n_it = c_left;
         for (int j_it = 0; j_it < n_it; ++j_it, ++it) {
             const bool more = it + 1 < it1;
+#if defined(GEMM_PHASES)
+            const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
+#endif
             if (more && GEMM_ABLATE < 1) load_next();      // global -> registers, in flight during the MFMAs
+#if defined(GEMM_PHASES)
+            const unsigned long long ph1 = __builtin_amdgcn_s_memtime();
+#endif
             const float* a_base = sA(cur) + (wm * (32 * TM) + r) * GEMM_LDS + 4 * hh;
             const float* b_base = sB(cur) + (wn * (32 * TN) + r) * GEMM_LDS + 4 * hh;
 #pragma unroll
@@ -307,16 +316,30 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
                     }
             }
+#if defined(GEMM_PHASES)
+            asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15]));
+            const unsigned long long ph2 = __builtin_amdgcn_s_memtime();
+            if (more) store_tile(cur ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long ph3 = __builtin_amdgcn_s_memtime();
+            if (more) { __syncthreads(); cur ^= 1; }
+            const unsigned long long ph4 = __builtin_amdgcn_s_memtime();
+            phs[0] += ph1 - ph0; phs[1] += ph2 - ph1; phs[2] += ph3 - ph2; phs[3] += ph4 - ph3; phs[4] += 1;
+#else
             if (more && GEMM_ABLATE < 2) {
                 store_tile(cur ^ 1);                       // other buffer: nobody reads it in this iteration
                 __syncthreads();
                 cur ^= 1;
             }
+#endif
         }
         if (GEMM_ABLATE < 3) flush(acc, sA(cur ^ 1));
         else asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15]));
         if (it < it1) decode(it);
     }
+#if defined(GEMM_PHASES)
+    if (args.dbg && tid == 0) for (int q = 0; q < 5; ++q) args.dbg[8 * g + q] = phs[q];
+#endif
 #if defined(GEMM_STAMP)
     if (args.dbg && tid == 0) {
         args.dbg[4 * g] = __builtin_amdgcn_s_memtime() - st0;
