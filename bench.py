@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="beam5", choices=["beam5", "greedy", "xe", "scst"])
+    ap.add_argument("--workload", default="beam5", choices=["beam5", "beam5idx", "greedy", "xe", "scst"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24)
     args = ap.parse_args()
@@ -224,7 +224,18 @@ def main():
         seed = 1000 + 10 * rank + i
         batches.append((torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed)).to(dev),
                         torch.from_numpy(synth.make_ctrl(c["B"], c["L"], c["R"], c["D"], seed=seed)).to(dev)))
-    beam = BEAM if args.workload == "beam5" else 1
+    beam = BEAM if args.workload in ("beam5", "beam5idx") else 1
+    indexed = args.workload == "beam5idx"
+    if indexed:
+        # index-list region format: the slots name rows of the image's own detection matrix instead of
+        # carrying copies of them; same shapes as the headline workload, decoded through vsr_prepare_indexed
+        from vsrcap.regions import IndexedRegions
+        batches = []
+        for i in range(2):
+            seed = 1000 + 10 * rank + i
+            det = torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed, min_valid=c["R0"])).to(dev)
+            idx = torch.from_numpy(synth.make_slot_indices(c["B"], c["L"], c["R"], c["R0"], seed=seed)).to(dev)
+            batches.append((det, IndexedRegions(det, idx)))
 
     def one_step(i):
         det, ctrl = batches[i & 1]
@@ -258,8 +269,8 @@ def main():
         tokens = world * c["B"] * c["T"] * args.steps
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         line = {
-            "metric": "decoded tokens/sec at batch=100, beam=5, 36x2048 regions" if beam > 1 else
-                      "decoded tokens/sec, greedy, batch=100, 36x2048 regions",
+            "metric": ("decoded tokens/sec at batch=100, beam=5, 36x2048 regions" + (", index-list region format" if indexed else ""))
+                      if beam > 1 else "decoded tokens/sec, greedy, batch=100, 36x2048 regions",
             "value": tokens / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -268,11 +279,25 @@ def main():
                        "beam": beam, "batch_per_gpu": c["B"], "seq_len": c["T"], "parallelism": "images sharded, dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": measured_traffic() if beam > 1 else None, "launches": gemm_n,
+                         "traffic": measured_traffic() if (beam > 1 and not indexed) else None, "launches": gemm_n,
                          "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1), "gemm_share_of_wall": gemm_ms * 1e-3 / dt,
                          "algorithmic_flops_per_launch": gemm_flops / max(gemm_n, 1)},
         }
-        if world == 1 and not args.no_cpu:
+        if indexed:
+            # the same data through the dense wire format of the reference (regions materialised once, outside the timing)
+            dense = [(d, r.dense().contiguous()) for d, r in batches]
+            with torch.no_grad():
+                for i in range(2):
+                    m.beam_search(dense[i & 1], [EOS, -1], beam, 1)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    m.beam_search(dense[i & 1], [EOS, -1], beam, 1)
+                torch.cuda.synchronize(dev)
+            line["config"]["dense_format_same_data_tokens_per_s"] = c["B"] * c["T"] * args.steps / (time.perf_counter() - t1)
+            line["config"]["region_bytes_per_batch"] = {"index_lists": int(batches[0][1].slot_idx.numel() * 4),
+                                                        "dense": int(dense[0][1].numel() * 4)}
+        if world == 1 and not args.no_cpu and not indexed:
             line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam)
         print(json.dumps(line))
     if world > 1:

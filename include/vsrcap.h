@@ -111,6 +111,36 @@ size_t vsr_workspace_bytes(const vsr_handle* h, int32_t B, int32_t R0, int32_t L
 int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R0, const float* regions, int32_t L, int32_t R,
                 int32_t beam, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- index-list region format (decode side) -------------------------------------------
+ * The reference's callers materialise statics[1] as a dense (rows, L, R, D) copy of detection features:
+ * data/field.py:44-61 (COCOControlSequenceField._fill: np.take of det_features rows per slot) and
+ * coco_scripts/eval_coco.py:222-247 (slot permutation, compaction, last-slot replication, then one
+ * beam_search_v call per image with det expanded to n_caps rows).  The decoder itself only needs to know
+ * WHICH row of the image's feature matrix each slot entry is.  These entry points take that instead:
+ *   det       (n_img, R0, D)  pooled detections, one per IMAGE          (statics[0] before the .expand)
+ *   bank      (n_img, Rb, D)  the feature matrix the slots were taken from (may alias det when Rb == R0)
+ *   row_img   (B) int32 or NULL: image of decoder row b (several captions per image); NULL = identity, B == n_img
+ *   slot_idx  (B, L, R) int32: bank row of slot entry (b, l, r), -1 = padding row
+ * and are defined as vsr_prepare() on the dense tensor regions[b,l,r,:] = slot_idx < 0 ? 0 : bank[row_img[b], slot_idx, :]
+ * (same masks, same tokens).  att_va runs over the n_img * Rb bank rows instead of B * L * R copies.
+ * An index outside [-1, Rb) or an image outside [0, n_img) fails the call (reported through the same single
+ * read-back as the row count).  The training calls reject a handle prepared this way. */
+size_t vsr_workspace_bytes_indexed(const vsr_handle* h, int32_t B, int32_t R0, int32_t n_img, int32_t Rb, int32_t L,
+                                   int32_t R, int32_t beam);
+int vsr_prepare_indexed(vsr_handle* h, const float* det, int32_t n_img, int32_t R0, const float* bank, int32_t Rb,
+                        const int32_t* row_img, int32_t B, const int32_t* slot_idx, int32_t L, int32_t R, int32_t beam,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* mask[i] = (sum_d rows[i, :] != 0), the reference's zero-row test (controllable_captioning.py:126,159) */
+int vsr_row_mask(const float* rows, int64_t n_rows, int32_t D, float* mask, void* stream);
+/* eval_coco.py:222-241 on index lists, N captions at once:
+ *   rank (N, L) int32: final_rank padded with -1 (position j takes slot rank[j]); slots whose rows are all
+ *   padding / all-zero bank rows (bank_mask from vsr_row_mask over the bank, NULL = every indexed row counts)
+ *   are dropped, the last kept slot is replicated to the end (:230-234); verbs_out[j] = verbs[rank[j]] or -1
+ *   where the permutation has no row j, NOT compacted (:237-238).  verbs / verbs_out (N, L) fp32 or NULL. */
+int vsr_reorder_slots(const int32_t* slot_idx, const int32_t* rank, const float* verbs, const float* bank_mask,
+                      const int32_t* row_img, int32_t N, int32_t L, int32_t R, int32_t Rb, int32_t* slot_out,
+                      float* verbs_out, void* stream);
+
 /* ---- decode loops --------------------------------------------------------------------------------- */
 /* verbs: (B,L) fp32 or NULL (-1 = no verb) -> step_v semantics; gt as in beam_search_v(..., gt=) */
 /* CaptioningModel.test (:38-52): words/gates (B,T) int64 */

@@ -33,10 +33,12 @@ __device__ __forceinline__ int xcd_item(int n) {
 
 // ---------------------------------------------------------------------------------------------- prepare
 // pooled descriptor vbar[b] = sum_r det[b,r,:] / #(rows with non-zero sum)           (step :126-128)
-__global__ __launch_bounds__(256) void k_pool(const float* __restrict__ det, int R0, int D, float* __restrict__ vbar) {
+// row_img (optional): decoder row b pools the detections of image row_img[b] (several captions of one image)
+__global__ __launch_bounds__(256) void k_pool(const float* __restrict__ det, const int* __restrict__ row_img, int R0, int D,
+                                              float* __restrict__ vbar) {
     __shared__ float cnt_s[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* X = det + (long long)b * R0 * D;
+    const float* X = det + (long long)(row_img ? row_img[b] : b) * R0 * D;
     float cnt = 0.f;
     for (int r = wave; r < R0; r += 4) {
         float s = 0.f;
@@ -92,6 +94,64 @@ __global__ __launch_bounds__(1024) void k_compact_rows(const float* __restrict__
     for (int r = r0; r < r1; ++r)
         if (mask[r] != 0.f) vlist[pos++] = r;
     if (tid == 1023) *count = part[1023];
+}
+
+// Index-list region format: slot entry (b, l, r) names row slot_idx[b,l,r] of image row_img[b]'s feature
+// bank (-1 = padding).  ridx = absolute bank row (or -1), rmask = the reference's row mask of the dense tensor the list
+// stands for (an all-zero bank row is masked exactly as its dense copy would be).  bad counts out-of-range indices.
+__global__ void k_index_rows(const int* __restrict__ slot_idx, const int* __restrict__ row_img, const float* __restrict__ bmask,
+                             int B, int LR, int Rb, int n_img, int* __restrict__ ridx, float* __restrict__ rmask,
+                             int* __restrict__ bad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * LR) return;
+    const int b = (int)(i / LR);
+    const int img = row_img ? row_img[b] : b;
+    const int id = slot_idx[i];
+    int row = -1;
+    if (id >= Rb || id < -1 || img < 0 || img >= n_img) atomicAdd(bad, 1);
+    else if (id >= 0) row = img * Rb + id;
+    ridx[i] = row;
+    rmask[i] = row >= 0 ? bmask[row] : 0.f;
+}
+
+// Slot re-ordering of the eval loop on index lists (eval_coco.py:222-241): one block per caption.
+//   recons[j] = slots[rank[j]] for j < len(rank) (rank padded with -1), empty otherwise      (:222-229 perm_matrix . slots)
+//   empty slots (no row with a non-zero bank row) are dropped, order kept                     (:230)
+//   the last kept slot is replicated to the end                                               (:232-234)
+//   verbs[j] = verbs_in[rank[j]] or -1 where the permutation has no row j; NOT compacted      (:237-238)
+__global__ __launch_bounds__(64) void k_reorder_slots(const int* __restrict__ slot_in, const int* __restrict__ rank,
+                                                      const float* __restrict__ verbs_in, const float* __restrict__ bmask,
+                                                      const int* __restrict__ row_img, int L, int R, int Rb,
+                                                      int* __restrict__ slot_out, float* __restrict__ verbs_out) {
+    extern __shared__ int sh[];
+    int* src = sh;                 // L: source slot of output position j after compaction, -1 = none
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int img = row_img ? row_img[n] : n;
+    const int* S = slot_in + (long long)n * L * R;
+    if (tid == 0) {
+        int kept = 0;
+        for (int j = 0; j < L; ++j) {
+            const int rk = rank[(long long)n * L + j];
+            bool live = false;
+            if (rk >= 0 && rk < L)
+                for (int r = 0; r < R && !live; ++r) {
+                    const int id = S[rk * R + r];
+                    live = id >= 0 && id < Rb && (!bmask || bmask[(long long)img * Rb + id] != 0.f);
+                }
+            if (live) src[kept++] = rk;
+        }
+        for (int j = kept; j < L; ++j) src[j] = kept > 0 ? src[kept - 1] : -1;
+    }
+    __syncthreads();
+    for (int i = tid; i < L * R; i += 64) {
+        const int j = i / R, r = i - j * R;
+        slot_out[(long long)n * L * R + i] = src[j] >= 0 ? S[src[j] * R + r] : -1;
+    }
+    if (verbs_in)
+        for (int j = tid; j < L; j += 64) {
+            const int rk = rank[(long long)n * L + j];
+            verbs_out[(long long)n * L + j] = (rk >= 0 && rk < L) ? verbs_in[(long long)n * L + rk] : -1.f;
+        }
 }
 
 // P[vlist[m]] = sum of the slabs' row m   (scatter of the compact projection back to the dense row index)
@@ -220,6 +280,7 @@ __global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__
 __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, const float* __restrict__ sa,
                                                 const float* __restrict__ sent, const float* __restrict__ P,
                                                 const float* __restrict__ regions, const float* __restrict__ rmask,
+                                                const int* __restrict__ ridx,
                                                 const int* __restrict__ slot, int fixed_slot, int rpi, int M, int L,
                                                 int R, int A, int D, const float* __restrict__ w_a,
                                                 const float* __restrict__ w_s, float* __restrict__ att,
@@ -228,6 +289,7 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     float* hA_s = sm;             // A
     float* z_s = sm + A;          // R + 1  (then alpha)
     float* red = z_s + R + 1;     // 8
+    int* ri_s = reinterpret_cast<int*>(red + 8);   // R: row of P / regions behind slot entry r (dense: its own row)
     const int row = xcd_item(M);
     if (row < 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -235,11 +297,14 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     const int k = slot ? slot[row] : fixed_slot;
     const long long sl = (long long)img * L + k;
     for (int a = tid; a < A; a += 256) hA_s[a] = hA[(long long)row * A + a];
+    for (int r = tid; r < R; r += 256) {
+        const int e = ridx ? ridx[sl * R + r] : (int)(sl * R + r);
+        ri_s[r] = e < 0 ? 0 : e;                   // padding entries are masked and never dereferenced
+    }
     __syncthreads();
 
     // scores: wave w takes rows w, w+4, ... of [regions ; sentinel]; four rows per pass so that their projection
     // loads are all in flight before the first tanh (one L2 round trip per pass instead of one per row)
-    const float* Pk = P + sl * R * A;
     const float* mk_row = rmask + sl * R;
     for (int r0 = wave; r0 < R + 1; r0 += 16) {
         float sc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -248,7 +313,7 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = r0 + 4 * q;
-                const float* src = (r < R) ? Pk + (long long)r * A : sa + (long long)row * A;
+                const float* src = (r < R) ? P + (long long)ri_s[r] * A : sa + (long long)row * A;
                 // padding rows were never projected (att_va(0) = 0): their P entry is not defined, use the exact zero
                 const bool live = r < R + 1 && (r >= R || mk_row[r] != 0.f);
                 p[q] = live ? *reinterpret_cast<const float4*>(src + a) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -315,7 +380,6 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
 
     // weighted sum.  Rows with alpha == 0 (zero padding) are skipped: no HBM read for them.  Four region rows are in
     // flight per thread (independent loads) so that the 8 KB rows stream instead of paying one L2/HBM latency each.
-    const float* Xk = regions + sl * R * D;
     const float a0 = z_s[0];
     for (int d = tid * 4; d < D; d += 1024) {
         const float4 s = *reinterpret_cast<const float4*>(srow + d);
@@ -330,7 +394,7 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
             float4 x[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                x[q] = al[q] != 0.f ? *reinterpret_cast<const float4*>(Xk + (long long)(r + q) * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[q] = al[q] != 0.f ? *reinterpret_cast<const float4*>(regions + (long long)ri_s[r + q] * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 acc.x += al[q] * x[q].x; acc.y += al[q] * x[q].y; acc.z += al[q] * x[q].z; acc.w += al[q] * x[q].w;
@@ -339,7 +403,7 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
         for (; r < R; ++r) {
             const float al = z_s[r + 1];
             if (al != 0.f) {
-                const float4 x = *reinterpret_cast<const float4*>(Xk + (long long)r * D + d);
+                const float4 x = *reinterpret_cast<const float4*>(regions + (long long)ri_s[r] * D + d);
                 acc.x += al * x.x; acc.y += al * x.y; acc.z += al * x.z; acc.w += al * x.w;
             }
         }

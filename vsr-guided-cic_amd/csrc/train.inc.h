@@ -126,6 +126,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     if (!word_in || !logp_words || !logp_gates || !train_ws) return fail("vsr_train_forward: null tensor");
     Ctx& c = h->c;
     if (c.beam != 1 && c.Mmax != c.B) return fail("vsr_train_forward: prepare() must be called with beam = 1");
+    if (c.ridx) return fail("vsr_train_forward: index-list regions (vsr_prepare_indexed) are a decode-side format; train on dense region tensors (vsr_prepare)");
     if (!slots && T != c.L) return fail("vsr_train_forward: without a slot trace the regions must have one slot per step (T %d, L %d)", T, c.L);
     hipStream_t s = (hipStream_t)stream;
     const vsr_dims& d = h->d;
@@ -201,8 +202,8 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
                                B, H, A, D, g_t, hA, sent, sa, g1);
         }
         {
-            const size_t smem = (size_t)(A + c.R + 1 + 8) * sizeof(float);
-            hipLaunchKernelGGL(k_attend, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, hA, sa, sent, c.P, c.regions, c.rmask, slot, 0, 1, B, c.L,
+            const size_t smem = (size_t)(A + c.R + 1 + 8 + c.R) * sizeof(float);
+            hipLaunchKernelGGL(k_attend, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
                                c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
         }
         {   // S5

@@ -46,8 +46,12 @@ static int fail(const char* fmt, ...) {
 
 struct Ctx {
     int B = 0, R0 = 0, L = 0, R = 0, beam = 1, Mmax = 0;
+    int n_img = 0, Rb = 0;       // index-list region format: images and rows per image of the feature bank (0 = dense regions)
     const float* det = nullptr;
-    const float* regions = nullptr;
+    const float* regions = nullptr;   // dense (B, L, R, D) region tensor, or the (n_img, Rb, D) feature bank
+    const int* ridx = nullptr;   // (B, L, R) absolute bank row per slot entry (index-list format) or null
+    int* ridx_buf = nullptr;
+    float* bmask = nullptr;      // row masks of the rows att_va runs over (dense: = rmask)
     float *vbar, *vproj, *vproj2, *P, *rmask;
     int *vlist, *nvalid_dev;     // non-padding region rows (ascending) and their number
     int nvalid = 0;
@@ -110,13 +114,21 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     const vsr_dims& d = h->d;
     const size_t B = c.B, H = d.rnn_size, A = d.att_size, D = d.det_feat_size, V = d.vocab_size, T = d.seq_len;
     const size_t M = c.Mmax, rows = B * c.L * c.R;
+    const size_t prows = c.Rb > 0 ? (size_t)c.n_img * c.Rb : rows;      // rows the hoisted att_va projection covers
     Bump b{base};
     c.vbar = b.take<float>(B * D);
     c.vproj = b.take<float>(B * 6 * H);
     c.vproj2 = b.take<float>(B * 4 * H);
-    c.P = b.take<float>(rows * A);
+    c.P = b.take<float>(prows * A);
     c.rmask = b.take<float>(rows);
-    c.vlist = b.take<int>(rows);
+    if (c.Rb > 0) {
+        c.bmask = b.take<float>(prows);
+        c.ridx_buf = b.take<int>(rows);
+    } else {
+        c.bmask = c.rmask;
+        c.ridx_buf = nullptr;
+    }
+    c.vlist = b.take<int>(prows);
     c.nvalid_dev = b.take<int>(4);
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 4; ++j) c.st[i][j] = b.take<float>(M * H);
@@ -335,30 +347,51 @@ extern "C" size_t vsr_workspace_bytes(const vsr_handle* h, int32_t B, int32_t R0
     return carve(h, c, nullptr);
 }
 
+extern "C" size_t vsr_workspace_bytes_indexed(const vsr_handle* h, int32_t B, int32_t R0, int32_t n_img, int32_t Rb, int32_t L,
+                                              int32_t R, int32_t beam) {
+    if (!h || B <= 0 || L <= 0 || R <= 0 || beam <= 0 || n_img <= 0 || Rb <= 0) return 0;
+    Ctx c;
+    c.B = B; c.R0 = R0; c.L = L; c.R = R; c.beam = beam; c.Mmax = B * beam; c.n_img = n_img; c.Rb = Rb;
+    return carve(h, c, nullptr);
+}
+
 // ---------------------------------------------------------------------------------------------- prepare
-extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R0, const float* regions, int32_t L,
-                           int32_t R, int32_t beam, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!h || !h->bound) return fail("vsr_prepare: weights not bound");
-    if (!det || !regions || !workspace) return fail("vsr_prepare: null tensor");
-    if (B <= 0 || R0 <= 0 || L <= 0 || R <= 0) return fail("vsr_prepare: empty batch / regions");
-    if (beam < 1 || beam > VSR_MAX_BEAM) return fail("vsr_prepare: beam size %d not in [1, %d]", beam, VSR_MAX_BEAM);
-    if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail("vsr_prepare: workspace must be 16-byte aligned");
+// Both region formats.  Dense: regions = (B, L, R, D).  Index lists: regions = feature bank (n_img, Rb, D),
+// slot_idx = (B, L, R) rows of image row_img[b]'s bank (-1 = padding), det = (n_img, R0, D).
+static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const float* regions, int n_img, int Rb,
+                        const int* row_img, const int* slot_idx, int L, int R, int beam, void* workspace,
+                        size_t workspace_bytes, void* stream, const char* who) {
+    if (!h || !h->bound) return fail("%s: weights not bound", who);
+    if (!det || !regions || !workspace) return fail("%s: null tensor", who);
+    if (B <= 0 || R0 <= 0 || L <= 0 || R <= 0) return fail("%s: empty batch / regions", who);
+    if (beam < 1 || beam > VSR_MAX_BEAM) return fail("%s: beam size %d not in [1, %d]", who, beam, VSR_MAX_BEAM);
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail("%s: workspace must be 16-byte aligned", who);
+    const bool indexed = slot_idx != nullptr;
+    if (indexed && (n_img <= 0 || Rb <= 0)) return fail("%s: empty feature bank", who);
     hipStream_t s = (hipStream_t)stream;
     const vsr_dims& d = h->d;
     const vsr_weights& w = h->w;
     const int H = d.rnn_size, A = d.att_size, D = d.det_feat_size, E = d.input_encoding_size;
     Ctx& c = h->c;
     c.B = B; c.R0 = R0; c.L = L; c.R = R; c.beam = beam; c.Mmax = B * beam;
+    c.n_img = indexed ? n_img : 0; c.Rb = indexed ? Rb : 0;
     c.det = det; c.regions = regions;
     const size_t need = carve(h, c, reinterpret_cast<char*>(workspace));
-    if (need > workspace_bytes) return fail("vsr_prepare: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
+    if (need > workspace_bytes) return fail("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
+    c.ridx = c.ridx_buf;
     h->prepared = false;
     invalidate_train_ctx(h->tc);       // a saved forward refers to the hoisted tensors of the previous prepare()
 
     // pooled descriptor and region-row masks
-    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, s, det, R0, D, c.vbar);
-    const long long rows = (long long)B * L * R;
-    hipLaunchKernelGGL(k_rowmask, dim3(cdiv(rows, 4)), dim3(256), 0, s, regions, rows, D, c.rmask);
+    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, s, det, indexed ? row_img : nullptr, R0, D, c.vbar);
+    const long long rows = (long long)B * L * R;                         // slot entries
+    const long long prows = indexed ? (long long)n_img * Rb : rows;      // rows att_va runs over
+    hipLaunchKernelGGL(k_rowmask, dim3(cdiv(prows, 4)), dim3(256), 0, s, regions, prows, D, c.bmask);
+    if (indexed) {
+        HIPCHK(hipMemsetAsync(c.nvalid_dev, 0, 4 * sizeof(int), s));
+        hipLaunchKernelGGL(k_index_rows, dim3(cdiv(rows, 256)), dim3(256), 0, s, slot_idx, row_img, c.bmask, B, L * R, Rb, n_img,
+                           c.ridx_buf, c.rmask, c.nvalid_dev + 1);
+    }
     LAUNCHCHK();
 
     // hoisted vbar projections: columns [voff, voff + D) of the LSTM1 / gate input weights
@@ -393,11 +426,15 @@ extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R
         hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.vproj2);
         LAUNCHCHK();
     }
-    // att_va over the NON-PADDING region rows only (att_va(0) = 0): compact row list, gathered GEMM, scatter back.
-    // The row count has to reach the host to size the launch: the one place where this library waits for the stream.
-    hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, s, c.rmask, (int)rows, c.vlist, c.nvalid_dev);
-    HIPCHK(hipMemcpyAsync(&c.nvalid, c.nvalid_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    // att_va over the NON-PADDING rows only (att_va(0) = 0): compact row list, gathered GEMM, scatter back.
+    // The row count has to reach the host to size the launch: the one place where this library waits for the stream
+    // (the index-list format reports its out-of-range count through the same read-back).
+    hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, s, c.bmask, (int)prows, c.vlist, c.nvalid_dev);
+    int back[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(back, c.nvalid_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    c.nvalid = back[0];
+    if (indexed && back[1] != 0) return fail("%s: %d slot entries index outside the feature bank [-1, %d) or name an image outside [0, %d)", who, back[1], Rb, n_img);
     if (c.nvalid > 0) {
         GemmBuilder g;
         GemmProb& p0 = g.prob(c.nvalid, A, c.scratch, A);
@@ -410,6 +447,37 @@ extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R
         LAUNCHCHK();
     }
     h->prepared = true;
+    return 0;
+}
+
+extern "C" int vsr_prepare(vsr_handle* h, const float* det, int32_t B, int32_t R0, const float* regions, int32_t L,
+                           int32_t R, int32_t beam, void* workspace, size_t workspace_bytes, void* stream) {
+    return prepare_impl(h, det, B, R0, regions, 0, 0, nullptr, nullptr, L, R, beam, workspace, workspace_bytes, stream, "vsr_prepare");
+}
+
+extern "C" int vsr_prepare_indexed(vsr_handle* h, const float* det, int32_t n_img, int32_t R0, const float* bank, int32_t Rb,
+                                   const int32_t* row_img, int32_t B, const int32_t* slot_idx, int32_t L, int32_t R,
+                                   int32_t beam, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!slot_idx) return fail("vsr_prepare_indexed: null slot index list");
+    return prepare_impl(h, det, B, R0, bank, n_img, Rb, row_img, slot_idx, L, R, beam, workspace, workspace_bytes, stream,
+                        "vsr_prepare_indexed");
+}
+
+extern "C" int vsr_row_mask(const float* rows, int64_t n_rows, int32_t D, float* mask, void* stream) {
+    if (!rows || !mask || n_rows <= 0 || D <= 0 || (D & 3)) return fail("vsr_row_mask: bad arguments");
+    hipLaunchKernelGGL(k_rowmask, dim3(cdiv(n_rows, 4)), dim3(256), 0, (hipStream_t)stream, rows, (long long)n_rows, D, mask);
+    LAUNCHCHK();
+    return 0;
+}
+
+extern "C" int vsr_reorder_slots(const int32_t* slot_idx, const int32_t* rank, const float* verbs, const float* bank_mask,
+                                 const int32_t* row_img, int32_t N, int32_t L, int32_t R, int32_t Rb, int32_t* slot_out,
+                                 float* verbs_out, void* stream) {
+    if (!slot_idx || !rank || !slot_out || N <= 0 || L <= 0 || R <= 0 || Rb <= 0) return fail("vsr_reorder_slots: bad arguments");
+    if (verbs && !verbs_out) return fail("vsr_reorder_slots: verbs given without an output");
+    hipLaunchKernelGGL(k_reorder_slots, dim3(N), dim3(64), (size_t)L * sizeof(int), (hipStream_t)stream, slot_idx, rank, verbs,
+                       bank_mask, row_img, L, R, Rb, slot_out, verbs_out);
+    LAUNCHCHK();
     return 0;
 }
 
@@ -502,8 +570,8 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     }
     // ---- attention
     {
-        const size_t smem = (size_t)(A + c.R + 1 + 8) * sizeof(float);
-        hipLaunchKernelGGL(k_attend, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, io.slot,
+        const size_t smem = (size_t)(A + c.R + 1 + 8 + c.R) * sizeof(float);
+        hipLaunchKernelGGL(k_attend, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
                            io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out);
     }
     // ---- S5

@@ -108,29 +108,45 @@ class ControllableCaptioningModel(CaptioningModel):
             self._verb_dev = device
         return verbs.to(device=device, dtype=torch.float32).contiguous()
 
+    def _prepare(self, eng, det, regions, beam):
+        """Hoisted per-image work for either region format: the reference's dense (B,L,R,D) tensor, or
+        vsrcap.regions.IndexedRegions (index lists into the image's feature bank; decode only)."""
+        from vsrcap.regions import IndexedRegions
+        if isinstance(regions, IndexedRegions):
+            return eng.prepare_indexed(det, regions.bank, regions.slot_idx, regions.row_img, beam, self._weights_version())
+        return eng.prepare(det, regions, beam, self._weights_version())
+
     # ------------------------------------------------------------------ loops (CaptioningModel hooks)
     def _run_forward(self, statics, seqs):
         det, (captions, ctrl_seq) = statics[0], seqs
         eng = self._engine(det.device)
         if captions.size(1) > self.seq_len:
             raise RuntimeError("captions longer than seq_len")
-        B = eng.prepare(det, ctrl_seq, 1, self._weights_version())
+        from vsrcap.regions import IndexedRegions
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if isinstance(ctrl_seq, IndexedRegions):
+                raise RuntimeError("IndexedRegions is a decode-side format: train on the dense region tensor (regions.dense())")
+            B = eng.prepare(det, ctrl_seq, 1, self._weights_version())
             from vsrcap.train import xe_forward_with_grad
             return xe_forward_with_grad(self, eng, det, captions, ctrl_seq)
+        B = self._prepare(eng, det, ctrl_seq, 1)
         return eng.xe_forward(B, det.device, captions)
 
     def _run_greedy(self, statics, verbs=None, gt=False):
         det, ctrl = statics[0], statics[1]
         eng = self._engine(det.device)
-        B = eng.prepare(det, ctrl, 1, self._weights_version())
+        B = self._prepare(eng, det, ctrl, 1)
         v = self._verbs(eng, statics[2], det.device) if len(statics) > 2 and statics[2] is not None else None
         return eng.greedy(B, det.device, v, gt)
 
     def _run_sample(self, statics, seed=None, forced=None):
         det, ctrl = statics[0], statics[1]
         eng = self._engine(det.device)
-        B = eng.prepare(det, ctrl, 1, self._weights_version())
+        from vsrcap.regions import IndexedRegions
+        with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if with_grad and isinstance(ctrl, IndexedRegions):
+            raise RuntimeError("IndexedRegions is a decode-side format: sample with gradients on the dense region tensor")
+        B = self._prepare(eng, det, ctrl, 1)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         outs, lps = eng.sample(B, det.device, seed, forced)
@@ -142,7 +158,7 @@ class ControllableCaptioningModel(CaptioningModel):
     def _run_beam(self, statics, eos_idxs, beam_size, out_size, with_verbs, gt):
         det, ctrl = statics[0], statics[1]
         eng = self._engine(det.device)
-        B = eng.prepare(det, ctrl, beam_size, self._weights_version())
+        B = self._prepare(eng, det, ctrl, beam_size)
         v = self._verbs(eng, statics[2], det.device) if with_verbs else None
         (w, g), (lw, lg), _ = eng.beam(B, det.device, beam_size, out_size, eos_idxs[0], eos_idxs[1], v, gt)
         if out_size == 1:
@@ -169,7 +185,7 @@ class ControllableCaptioningModel(CaptioningModel):
             outs, (s1, s2, _) = eng.step(1, 1, prev, ((h1, c1), (h2, c2), torch.zeros_like(slot)))
             # feeding the ground-truth word as "previous output" with gate 0 on a single slot IS teacher forcing
             return outs, (s1, s2, slot)
-        eng.prepare(det, statics[1], 1, self._weights_version())
+        self._prepare(eng, det, statics[1], 1)
         v = self._verbs(eng, statics[2], det.device) if with_verbs else None
         return eng.step(t, 1, prev_outputs, state, v, gt)
 

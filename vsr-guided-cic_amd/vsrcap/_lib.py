@@ -53,6 +53,10 @@ SIGNATURES = {
     "vsr_build_decode_cache": (I32, [P, P, SZ, P]),
     "vsr_workspace_bytes": (SZ, [P, I32, I32, I32, I32, I32]),
     "vsr_prepare": (I32, [P, P, I32, I32, P, I32, I32, I32, P, SZ, P]),
+    "vsr_workspace_bytes_indexed": (SZ, [P, I32, I32, I32, I32, I32, I32, I32]),
+    "vsr_prepare_indexed": (I32, [P, P, I32, I32, P, I32, P, I32, P, I32, I32, I32, P, SZ, P]),
+    "vsr_row_mask": (I32, [P, I64, I32, P, P]),
+    "vsr_reorder_slots": (I32, [P, P, P, P, P, I32, I32, I32, I32, P, P, P]),
     "vsr_greedy": (I32, [P, P, I32, P, P, P]),
     "vsr_sample": (I32, [P, U64, P, P, P, P, P, P, P]),
     "vsr_beam": (I32, [P, I32, I32, I64, I64, P, I32, P, P, P, P, P, P]),

@@ -118,6 +118,63 @@ class Engine:
         self._prep_key = key
         return B
 
+    def prepare_indexed(self, det, bank, slot_idx, row_img, beam, weights_version=None):
+        """Index-list region format (include/vsrcap.h, vsr_prepare_indexed): det (n_img,R0,D), bank (n_img,Rb,D),
+        slot_idx (B,L,R) int32 rows of the row's image bank (-1 = padding), row_img (B) int32 or None."""
+        det = _f32(det, "detections")
+        bank = _f32(bank, "feature bank")
+        if det.dim() != 3 or bank.dim() != 3 or slot_idx.dim() != 3 or det.size(0) != bank.size(0) or det.size(2) != bank.size(2):
+            raise RuntimeError("expected detections (n_img,R0,D), bank (n_img,Rb,D), slot_idx (B,L,R); got %s, %s, %s"
+                               % (tuple(det.shape), tuple(bank.shape), tuple(slot_idx.shape)))
+        if det.size(2) != self.dims.det_feat_size:
+            raise RuntimeError("feature size %d != det_feat_size %d" % (det.size(2), self.dims.det_feat_size))
+        if not slot_idx.is_cuda or slot_idx.dtype != torch.int32:
+            raise RuntimeError("slot_idx must be an int32 GPU tensor (got %s on %s)" % (slot_idx.dtype, slot_idx.device))
+        slot_idx = slot_idx.contiguous()
+        n_img, R0, _ = det.shape
+        Rb = bank.size(1)
+        B, L, R = slot_idx.shape
+        if row_img is None:
+            if B != n_img:
+                raise RuntimeError("slot_idx has %d rows for %d images: pass row_img" % (B, n_img))
+        else:
+            if not row_img.is_cuda or row_img.dtype != torch.int32 or row_img.numel() != B:
+                raise RuntimeError("row_img must be an int32 GPU tensor with one entry per row of slot_idx")
+            row_img = row_img.contiguous()
+        key = ("idx", det.data_ptr(), det._version, bank.data_ptr(), bank._version, slot_idx.data_ptr(), slot_idx._version,
+               None if row_img is None else (row_img.data_ptr(), row_img._version), B, n_img, R0, Rb, L, R, beam,
+               self._bound_ptrs, weights_version)
+        if key == self._prep_key:
+            return B
+        need = self.lib.vsr_workspace_bytes_indexed(self.h, B, R0, n_img, Rb, L, R, beam)
+        if need == 0:
+            raise RuntimeError("vsr_workspace_bytes_indexed rejected the shapes")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != det.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=det.device)
+        self._prep_key = None
+        _lib.check(self.lib.vsr_prepare_indexed(self.h, _ptr(det), n_img, R0, _ptr(bank), Rb, _ptr(row_img), B, _ptr(slot_idx),
+                                                L, R, beam, _ptr(self._ws), self._ws.numel(), self._stream(det.device)))
+        self._keep = (det, bank, slot_idx, row_img)      # borrowed by the library until the next prepare
+        self._prep_key = key
+        return B
+
+    def row_mask(self, rows):
+        """(n, D) fp32 GPU rows -> (n,) fp32 mask of rows whose sum is not zero (the reference's zero-row test)."""
+        rows = _f32(rows, "rows")
+        flat = rows.reshape(-1, rows.size(-1))
+        out = torch.empty(flat.size(0), dtype=torch.float32, device=rows.device)
+        _lib.check(self.lib.vsr_row_mask(_ptr(flat), flat.size(0), flat.size(1), _ptr(out), self._stream(rows.device)))
+        return out.reshape(rows.shape[:-1])
+
+    def reorder_slots(self, slot_idx, rank, verbs, bank_mask, row_img, Rb):
+        """eval_coco.py:222-241 on index lists (vsr_reorder_slots): returns (slot_idx_out, verbs_out or None)."""
+        N, L, R = slot_idx.shape
+        out = torch.empty_like(slot_idx)
+        vout = torch.empty(N, L, dtype=torch.float32, device=slot_idx.device) if verbs is not None else None
+        _lib.check(self.lib.vsr_reorder_slots(_ptr(slot_idx), _ptr(rank), _ptr(verbs), _ptr(bank_mask), _ptr(row_img), N, L, R, Rb,
+                                              _ptr(out), _ptr(vout), self._stream(slot_idx.device)))
+        return out, vout
+
     def _stream(self, dev):
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 

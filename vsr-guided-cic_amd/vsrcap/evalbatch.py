@@ -31,3 +31,18 @@ def beam_search_v_batched(model, items, eos_idxs, beam_size=5, out_size=1, gt=Fa
         res.append(([o[lo:lo + n] for o in outs], [l[lo:lo + n] for l in lps]))
         lo += n
     return res
+
+
+def beam_search_v_indexed(model, detections, bank, slot_idx, row_img, final_ranks, verb_list, eos_idxs, beam_size=5, out_size=1,
+                          gt=False):
+    """The whole of eval_coco.py:222-249 for a batch of images on the GPU, in the index-list region format.
+
+    detections (n_img, R0, D) and bank (n_img, Rb, D): one entry per IMAGE (no `.expand` to n_caps rows, :242);
+    slot_idx (N, L, R) int32: the slots of every caption row as rows of its image's bank (vsrcap.regions.fill_region_indices);
+    row_img (N) int32: image of each caption row; final_ranks: the reference's `final_rank` per caption row (:216-221);
+    verb_list (N, L): `verb_list[i][idx]` per caption row.  Returns what ONE model.beam_search_v call over all N rows returns."""
+    from .regions import IndexedRegions, reorder_slots
+    eng = model._engine(detections.device)
+    regions = IndexedRegions(bank, slot_idx, row_img)
+    regions, verbs = reorder_slots(eng, regions, final_ranks, verb_list)
+    return model.beam_search_v((detections, regions, verbs), eos_idxs=eos_idxs, beam_size=beam_size, out_size=out_size, gt=gt)

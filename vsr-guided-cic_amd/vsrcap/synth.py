@@ -145,6 +145,19 @@ def make_ctrl(B, L, R, D, seed=0):
     return x
 
 
+def make_slot_indices(B, L, R, Rb, seed=0):
+    """(B, L, R) int32 index lists into an (Rb)-row feature bank, -1 = padding: per (row, slot) the n in [1, min(R, Rb)]
+    bank rows with the smallest hash keys, ascending (what np.unique gives field.py:52-55)."""
+    key = hash_u01(B * L * Rb, 11, seed).reshape(B, L, Rb)
+    n = hash_int(B * L, 1, min(R, Rb) + 1, 12, seed).reshape(B, L)
+    order = np.argsort(key, axis=-1, kind="stable")          # a random permutation of the bank rows per slot
+    idx = np.full((B, L, R), -1, dtype=np.int32)
+    for b in range(B):
+        for l in range(L):
+            idx[b, l, :n[b, l]] = np.sort(order[b, l, :n[b, l]])
+    return idx
+
+
 def make_verbs(B, L, n_verbs, seed=0, p=0.15):
     """(B, L) float64 (as eval_coco.py:240 builds it): -1 = no verb, else a verb id in [0, n_verbs)."""
     u = hash_u01(B * L, 5, seed).reshape(B, L)
