@@ -1,7 +1,8 @@
 // Pointwise / reduction kernels of the decoder step (everything that is not a GEMM).
 // Reference equations: /root/reference/models/controllable_captioning.py:117-190 (step), :192-297 (step_v);
 // loops: /root/reference/models/CaptioningModel.py:38-76 (greedy, sampling), :116-294 (beam search).
-// All arithmetic is fp32 with accurate expf/tanhf/logf (no fast-math), wave64 shuffles for reductions.
+// All arithmetic is fp32 with accurate expf/tanhf/logf (no fast-math), wave64 shuffles for reductions.  One exception,
+// measured and bounded: the ~19 000 tanh per row-step of the attention scores use tanhf() below.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -272,12 +273,14 @@ __global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__
 }
 
 // adaptive attention over [sentinel ; regions of the current slot]                    (step :158-171, :187)
-// one 256-thread workgroup per row; regions / projections are indexed by (image, slot), never copied.
+// one workgroup per row (512 threads at D >= 2048: one float4 column group per thread, half the dependent load
+// rounds of the weighted sum; results do not depend on the size); regions / projections are indexed by (image, slot), never copied.
 //   z_det[r] = w_a . tanh(P[img,slot,r,:] + hA)      z_sent = w_s . tanh(sa + hA)
 //   alpha    = softmax([z_sent ; z_det]) * mask ; alpha /= sum(alpha)
 //   att      = alpha_0 * sentinel + sum_r alpha_r * regions[img,slot,r,:]
 //   zsum     = sum_r mask_r * z_det[r]   (raw logits: the "shift" logit of the gate)
-__global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, const float* __restrict__ sa,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_attend(const float* __restrict__ hA, const float* __restrict__ sa,
                                                 const float* __restrict__ sent, const float* __restrict__ P,
                                                 const float* __restrict__ regions, const float* __restrict__ rmask,
                                                 const int* __restrict__ ridx,
@@ -292,12 +295,13 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     int* ri_s = reinterpret_cast<int*>(red + 8);   // R: row of P / regions behind slot entry r (dense: its own row)
     const int row = xcd_item(M);
     if (row < 0) return;
+    constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img = row / rpi;
     const int k = slot ? slot[row] : fixed_slot;
     const long long sl = (long long)img * L + k;
-    for (int a = tid; a < A; a += 256) hA_s[a] = hA[(long long)row * A + a];
-    for (int r = tid; r < R; r += 256) {
+    for (int a = tid; a < A; a += NT) hA_s[a] = hA[(long long)row * A + a];
+    for (int r = tid; r < R; r += NT) {
         const int e = ridx ? ridx[sl * R + r] : (int)(sl * R + r);
         ri_s[r] = e < 0 ? 0 : e;                   // padding entries are masked and never dereferenced
     }
@@ -306,13 +310,13 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     // scores: wave w takes rows w, w+4, ... of [regions ; sentinel]; four rows per pass so that their projection
     // loads are all in flight before the first tanh (one L2 round trip per pass instead of one per row)
     const float* mk_row = rmask + sl * R;
-    for (int r0 = wave; r0 < R + 1; r0 += 16) {
+    for (int r0 = wave; r0 < R + 1; r0 += 4 * NW) {
         float sc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int a = lane * 4; a < A; a += 256) {
             float4 p[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = r0 + 4 * q;
+                const int r = r0 + NW * q;
                 const float* src = (r < R) ? P + (long long)ri_s[r] * A : sa + (long long)row * A;
                 // padding rows were never projected (att_va(0) = 0): their P entry is not defined, use the exact zero
                 const bool live = r < R + 1 && (r >= R || mk_row[r] != 0.f);
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
             const float4 ws = *reinterpret_cast<const float4*>(w_s + a);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = r0 + 4 * q;
+                const int r = r0 + NW * q;
                 const float4 w = (r < R) ? wa : ws;
                 sc[q] += w.x * tanhf(p[q].x + h.x);
                 sc[q] += w.y * tanhf(p[q].y + h.y);
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = r0 + 4 * q;
+            const int r = r0 + NW * q;
             const float v = wave_sum(sc[q]);
             if (lane == 0 && r < R + 1) z_s[(r < R) ? r + 1 : 0] = v;
         }
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     // sentinel row-sum for its mask
     const float* srow = sent + (long long)row * D;
     float ss = 0.f;
-    for (int d = tid * 4; d < D; d += 1024) {
+    for (int d = tid * 4; d < D; d += 4 * NT) {
         const float4 v = *reinterpret_cast<const float4*>(srow + d);
         ss += (v.x + v.y) + (v.z + v.w);
     }
@@ -350,7 +354,9 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     __syncthreads();
 
     if (wave == 0) {
-        const float m0 = (((red[0] + red[1]) + (red[2] + red[3])) != 0.f) ? 1.f : 0.f;
+        float ssum = 0.f;
+        for (int w = 0; w < NW; ++w) ssum += red[w];
+        const float m0 = (ssum != 0.f) ? 1.f : 0.f;
         const float* mk = rmask + sl * R;
         // R + 1 <= 64 handled by one pass per 64 entries
         float mx = -INFINITY;
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(256) void k_attend(const float* __restrict__ hA, co
     // weighted sum.  Rows with alpha == 0 (zero padding) are skipped: no HBM read for them.  Four region rows are in
     // flight per thread (independent loads) so that the 8 KB rows stream instead of paying one L2/HBM latency each.
     const float a0 = z_s[0];
-    for (int d = tid * 4; d < D; d += 1024) {
+    for (int d = tid * 4; d < D; d += 4 * NT) {
         const float4 s = *reinterpret_cast<const float4*>(srow + d);
         float4 acc = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
         int r = 0;
@@ -437,33 +443,40 @@ __global__ void k_lstm2(const float* __restrict__ pre, int nsplit, long long str
 
 // shift-gate log-probabilities: z_g = w_g . tanh(att_ga g_t + hA); gate = log_softmax([z_g, zsum])   (:184-188)
 // verb-forced rows get [-1e3, 0] (step_v :271, :295).  one wave per row.
-__global__ __launch_bounds__(256) void k_gatelogit(const float* __restrict__ ga, int nsplit, long long stride,
-                                                   const float* __restrict__ hA, const float* __restrict__ w_g,
-                                                   const float* __restrict__ zsum, const float* __restrict__ verbs,
-                                                   const int* __restrict__ slot, int rpi, int L, int M, int A,
-                                                   float* __restrict__ lg, long long lg_stride) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int lane = threadIdx.x & 63;
+struct GateLogitArgs {
+    const float* ga; int nsplit; long long stride;       // (nsplit, M, A) raw sums of att_ga(g_t)
+    const float* hA; const float* w_g; const float* zsum; const float* verbs; const int* slot;
+    int rpi, L, M, A;
+    float* lg; long long lg_stride;
+};
+
+// one wave per row
+__device__ __forceinline__ void gatelogit_row(const GateLogitArgs& g, int row, int lane) {
     float s = 0.f;
-    for (int a = lane; a < A; a += 64) {
-        float g = 0.f;
-        for (int k = 0; k < nsplit; ++k) g += ga[k * stride + (long long)row * A + a];
-        s += w_g[a] * tanhf(g + hA[(long long)row * A + a]);
+    for (int a = lane; a < g.A; a += 64) {
+        float x = 0.f;
+        for (int k = 0; k < g.nsplit; ++k) x += g.ga[k * g.stride + (long long)row * g.A + a];
+        s += g.w_g[a] * tanhf(x + g.hA[(long long)row * g.A + a]);
     }
     s = wave_sum(s);
     if (lane == 0) {
-        const float a = s, b = zsum[row];
+        const float a = s, b = g.zsum[row];
         const float mx = fmaxf(a, b);
         const float lse = mx + logf(expf(a - mx) + expf(b - mx));
         float l0 = a - lse, l1 = b - lse;
-        if (verbs) {
-            const float v = verbs[(long long)(row / rpi) * L + slot[row]];
+        if (g.verbs) {
+            const float v = g.verbs[(long long)(row / g.rpi) * g.L + g.slot[row]];
             if (v != -1.f) { l0 = -1e3f; l1 = 0.f; }
         }
-        lg[(long long)row * lg_stride] = l0;
-        lg[(long long)row * lg_stride + 1] = l1;
+        g.lg[(long long)row * g.lg_stride] = l0;
+        g.lg[(long long)row * g.lg_stride + 1] = l1;
     }
+}
+
+__global__ __launch_bounds__(256) void k_gatelogit(const GateLogitArgs g) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= g.M) return;
+    gatelogit_row(g, row, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------------------------- vocab rows
@@ -496,19 +509,26 @@ enum VocabMode { VM_TOPK = 0, VM_SAMPLE = 1, VM_FORCED = 2, VM_FULL = 3 };
 //   VM_FORCED log-prob of a given id (sampling replay)
 //   VM_FULL   the whole log_softmax row is written to full_out             (step :178, forward :34)
 // Verb-forced rows (step_v :268-293) emit one word with log-prob 0 and -1e6 elsewhere.
-template <int K>
-__global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits, int nsplit, long long stride,
+template <int K, int NT>
+__global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, int nsplit, long long stride,
                                                const float* __restrict__ bias, int M, int V, int mode,
                                                float* __restrict__ top_v, int* __restrict__ top_i,
                                                float* __restrict__ full_out, long long full_stride,
                                                const int* __restrict__ forced, uint64_t seed, uint32_t t,
                                                const float* __restrict__ verbs, const int* __restrict__ slot, int rpi,
                                                int L, int gt, const int* __restrict__ vt_ptr,
-                                               const int* __restrict__ vt_ids, int n_verbs, int lds_row) {
-    __shared__ float sv[256 * K];
-    __shared__ int si[256 * K];
-    __shared__ float red[8];
-    __shared__ int redi[8];
+                                               const int* __restrict__ vt_ids, int n_verbs, int lds_row,
+                                               const GateLogitArgs gate) {
+    constexpr int NW = NT / 64;
+    if ((int)blockIdx.x >= M) {              // tail blocks: the gate logits of this step (independent of the vocabulary rows;
+        const int grow = ((int)blockIdx.x - M) * NW + (int)(threadIdx.x >> 6);      // they ride in this launch)
+        if (grow < gate.M) gatelogit_row(gate, grow, threadIdx.x & 63);
+        return;
+    }
+    __shared__ float sv[NT * K];
+    __shared__ int si[NT * K];
+    __shared__ float red[2 * NW];
+    __shared__ int redi[NW];
     __shared__ int pick_s;
     extern __shared__ float lrow[];          // V floats when the launch passes dynamic LDS: the combined row is
     const bool use_lds = lds_row != 0;       // summed from the slabs ONCE and the later passes read it from LDS
@@ -543,7 +563,7 @@ __global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits,
         __syncthreads();
         const int pick = pick_s;
         if (mode == VM_FULL) {
-            for (int v = tid; v < V; v += 256) full_out[(long long)row * full_stride + v] = (v == pick) ? 0.f : -1e6f;
+            for (int v = tid; v < V; v += NT) full_out[(long long)row * full_stride + v] = (v == pick) ? 0.f : -1e6f;
         } else if (mode == VM_TOPK) {
             if (tid < K) {   // the forced word first, then the lowest other ids at -1e6 (ties are arbitrary in the reference)
                 int id = (tid == 0) ? pick : ((tid - 1 < pick) ? tid - 1 : tid);
@@ -558,53 +578,74 @@ __global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits,
         return;
     }
 
-    // ---- pass 1: max and per-thread top-K (of logits, or of Gumbel-perturbed logits when sampling)
-    float tv[K];
-    int ti[K];
-#pragma unroll
-    for (int q = 0; q < K; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
+    // ---- pass 1: combined row (slabs + bias) -> LDS, row max, and every thread's single best key (logit, or
+    // Gumbel-perturbed logit when sampling).  No per-thread top-K list: with 64 lanes some lane inserts at almost every
+    // element, so a wave paid the whole insertion chain per element (5 800 VALU instructions per wave at K = 5).
+    float bkey = -INFINITY;
+    int bidx = 0x7fffffff;
     float mx = -INFINITY;
     const int V4 = (V + 3) & ~3;
     const bool vec = ((V & 3) == 0);
-    for (int v0 = tid * 4; v0 < V4; v0 += 1024) {
-        uint32_t rnd[4] = {0, 0, 0, 0};
-        if (mode == VM_SAMPLE) Philox::gen(seed, (uint32_t)(v0 >> 2), (uint32_t)row, t, 0u, rnd);
-        float xs[4] = {0.f, 0.f, 0.f, 0.f};
+    // Slab sums for VU float4 groups per thread are loaded together (every slab of every group in flight at once).
+    constexpr int VU = 5, KU = NT == 512 ? 2 : 4;      // 512 threads: <= 128 VGPRs so that two rows share a CU
+    for (int vb = tid * 4; vb < V4; vb += 4 * NT * VU) {
+        float xs_all[VU][4];
         if (vec) {
-            const float4 b4 = *reinterpret_cast<const float4*>(bias + v0);
-            xs[0] = b4.x; xs[1] = b4.y; xs[2] = b4.z; xs[3] = b4.w;
-            for (int k = 0; k < nsplit; ++k) {
-                const float4 s4 = *reinterpret_cast<const float4*>(src + k * stride + v0);
-                xs[0] += s4.x; xs[1] += s4.y; xs[2] += s4.z; xs[3] += s4.w;
+            float4 part[VU][KU + 1];
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int v0 = vb + 4 * NT * u;
+                const bool in = v0 < V4;
+                part[u][0] = in ? *reinterpret_cast<const float4*>(bias + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < KU; ++k)
+                    part[u][k + 1] = (in && k < nsplit) ? *reinterpret_cast<const float4*>(src + k * stride + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < VU; ++u) {
+                const int v0 = vb + 4 * NT * u;
+                float4 a = part[u][0];
+#pragma unroll
+                for (int k = 0; k < KU; ++k)
+                    if (k < nsplit) { a.x += part[u][k + 1].x; a.y += part[u][k + 1].y; a.z += part[u][k + 1].z; a.w += part[u][k + 1].w; }
+                if (v0 < V4)
+                    for (int k = KU; k < nsplit; ++k) {        // deeper splits than KU: the tail of the slab list, in order
+                        const float4 s4 = *reinterpret_cast<const float4*>(src + k * stride + v0);
+                        a.x += s4.x; a.y += s4.y; a.z += s4.z; a.w += s4.w;
+                    }
+                xs_all[u][0] = a.x; xs_all[u][1] = a.y; xs_all[u][2] = a.z; xs_all[u][3] = a.w;
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (v0 + e < V) {
-                    float x = bias[v0 + e];
-                    for (int k = 0; k < nsplit; ++k) x += src[k * stride + v0 + e];
-                    xs[e] = x;
+            for (int u = 0; u < VU; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = vb + 4 * NT * u + e;
+                    float x = 0.f;
+                    if (v < V) {
+                        x = bias[v];
+                        for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
+                    }
+                    xs_all[u][e] = x;
                 }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int v = v0 + e;
-            if (v < V) {
-                const float x = xs[e];
-                if (use_lds) lrow[v] = x;
-                mx = fmaxf(mx, x);
-                float key = x;
-                if (mode == VM_SAMPLE) key = x - logf(-logf(Philox::u01(rnd[e])));
-                if (mode == VM_TOPK || mode == VM_SAMPLE) {
-                    if (better(key, v, tv[K - 1], ti[K - 1])) {
-                        tv[K - 1] = key; ti[K - 1] = v;
+        for (int u = 0; u < VU; ++u) {
+            const int v0 = vb + 4 * NT * u;
+            if (v0 >= V4) break;
+            uint32_t rnd[4] = {0, 0, 0, 0};
+            if (mode == VM_SAMPLE) Philox::gen(seed, (uint32_t)(v0 >> 2), (uint32_t)row, t, 0u, rnd);
+            if (use_lds && vec) *reinterpret_cast<float4*>(lrow + v0) = make_float4(xs_all[u][0], xs_all[u][1], xs_all[u][2], xs_all[u][3]);
 #pragma unroll
-                        for (int q = K - 1; q > 0; --q)
-                            if (better(tv[q], ti[q], tv[q - 1], ti[q - 1])) {
-                                const float fv = tv[q]; tv[q] = tv[q - 1]; tv[q - 1] = fv;
-                                const int fi = ti[q]; ti[q] = ti[q - 1]; ti[q - 1] = fi;
-                            }
-                    }
+            for (int e = 0; e < 4; ++e) {
+                const int v = v0 + e;
+                if (v < V) {
+                    const float x = xs_all[u][e];
+                    if (use_lds && !vec) lrow[v] = x;
+                    mx = fmaxf(mx, x);
+                    float key = x;
+                    if (mode == VM_SAMPLE) key = x - logf(-logf(Philox::u01(rnd[e])));
+                    if (better(key, v, bkey, bidx)) { bkey = key; bidx = v; }
                 }
             }
         }
@@ -612,25 +653,100 @@ __global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits,
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
     __syncthreads();
 
-    // ---- pass 2: sum of exp
     auto getx = [&](int v) {
         if (use_lds) return lrow[v];
         float x = bias[v];
         for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
         return x;
     };
-    float se = 0.f;
-    for (int v = tid; v < V; v += 256) se += expf(getx(v) - mx);
-    se = wave_sum(se);
-    if (lane == 0) red[4 + wave] = se;
+    // block arg-max of one (value, index) pair per thread; every thread returns the winner
+    auto block_best = [&](float bv, int bi, float& gv, int& gi) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();                                   // red / redi of the previous round have been read
+        if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
+        __syncthreads();
+        gv = red[0];
+        gi = redi[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w)
+            if (better(red[w], redi[w], gv, gi)) { gv = red[w]; gi = redi[w]; }
+    };
+
+    // ---- threshold for the top-K: the K-th best of the NT thread maxima.  K distinct elements are >= it, so every one
+    // of the row's K best is too; pass 2 collects the (few) elements that reach it.
+    float tau = -INFINITY;
+    if (mode == VM_TOPK && K > 1 && NW >= K) {
+        // at least K waves: the K-th largest WAVE maximum is such a bound already (K distinct elements reach it), and the
+        // wave maxima are in `red` from the row-max reduction: no selection rounds at all
+        float wm[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) wm[w] = red[w];
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            float best = wm[0];
+            int at = 0;
+#pragma unroll
+            for (int w = 1; w < NW; ++w)
+                if (wm[w] > best) { best = wm[w]; at = w; }
+            tau = best;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if (w == at) wm[w] = -INFINITY;
+        }
+    } else if (mode == VM_TOPK && K > 1) {
+        float cv = bkey;
+        int ci = bidx;
+        for (int round = 0; round < K; ++round) {
+            float gv; int gi;
+            block_best(cv, ci, gv, gi);
+            if (ci == gi) { cv = -INFINITY; ci = 0x7fffffff; }      // taken (indices are unique; the -inf filler never matches a real one twice)
+            tau = gv;
+        }
+    }
+
+    // ---- pass 2: sum of exp, and the candidates for the top-K
+    __shared__ int ncand;
+    if (tid == 0) ncand = 0;
     __syncthreads();
-    const float lse = mx + logf((red[4] + red[5]) + (red[6] + red[7]));
+    float se = 0.f;
+    const bool collect = (mode == VM_TOPK && K > 1);
+    auto visit = [&](float x, int v) {
+        se += expf(x - mx);
+        if (collect && x >= tau) {
+            const int pos = atomicAdd(&ncand, 1);
+            if (pos < NT * K) { sv[pos] = x; si[pos] = v; }
+        }
+    };
+    if (use_lds && vec) {
+        for (int v0 = tid * 4; v0 < V; v0 += 4 * NT) {
+            const float4 x4 = *reinterpret_cast<const float4*>(lrow + v0);
+            visit(x4.x, v0); visit(x4.y, v0 + 1); visit(x4.z, v0 + 2); visit(x4.w, v0 + 3);
+        }
+    } else {
+        for (int v = tid; v < V; v += NT) visit(getx(v), v);
+    }
+    se = wave_sum(se);
+    __syncthreads();
+    if (lane == 0) red[NW + wave] = se;
+    __syncthreads();
+    float se_all = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) se_all += red[NW + w];
+    const float lse = mx + logf(se_all);
+    const int nc = ncand;
 
     if (mode == VM_FULL) {
-        for (int v = tid; v < V; v += 256) full_out[(long long)row * full_stride + v] = getx(v) - lse;
+        for (int v = tid; v < V; v += NT) full_out[(long long)row * full_stride + v] = getx(v) - lse;
         return;
     }
     if (mode == VM_FORCED) {
@@ -641,38 +757,83 @@ __global__ __launch_bounds__(256) void k_vocab(const float* __restrict__ logits,
         }
         return;
     }
-
-    // ---- block merge of the per-thread lists: K rounds of block arg-max
-#pragma unroll
-    for (int q = 0; q < K; ++q) { sv[tid * K + q] = tv[q]; si[tid * K + q] = ti[q]; }
-    __syncthreads();
-    int head = 0;   // my list is sorted: entries before head are already taken
-    const int nk = (mode == VM_SAMPLE) ? 1 : K;
-    for (int round = 0; round < nk; ++round) {
-        float bv = (head < K) ? sv[tid * K + head] : -INFINITY;
-        int bi = (head < K) ? si[tid * K + head] : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-        }
-        if (lane == 0) { red[wave] = bv; redi[wave] = bi; }
-        __syncthreads();
-        float gv = red[0];
-        int gi = redi[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (better(red[w], redi[w], gv, gi)) { gv = red[w]; gi = redi[w]; }
-        if (head < K && si[tid * K + head] == gi) ++head;
+    if (mode == VM_SAMPLE || K == 1) {                     // one winner: the best thread maximum
+        float gv; int gi;
+        block_best(bkey, bidx, gv, gi);
         if (tid == 0) {
-            if (mode == VM_SAMPLE) {
-                top_v[row] = getx(gi) - lse;
-                top_i[row] = gi;
-            } else {
+            top_v[row] = (mode == VM_SAMPLE ? getx(gi) : gv) - lse;
+            top_i[row] = gi;
+        }
+        return;
+    }
+    if (nc <= 64) {
+        // ---- the usual case, a handful of candidates: wave 0 alone picks the K best, one candidate per lane
+        if (wave != 0) return;
+        float cv = lane < nc ? sv[lane] : -INFINITY;
+        int ci = lane < nc ? si[lane] : 0x7fffffff;
+        for (int round = 0; round < K; ++round) {
+            float bv = cv;
+            int bi = ci;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            }
+            if (ci == bi) { cv = -INFINITY; ci = 0x7fffffff; }
+            if (lane == 0) {
+                top_v[(long long)row * K + round] = bv - lse;
+                top_i[(long long)row * K + round] = bi;
+            }
+        }
+        return;
+    }
+    if (nc <= NT * K) {
+        // ---- K rounds of block arg-max over the candidate list (<= K entries per thread, normally <= 1 in total per thread)
+        float lv[K];
+        int li[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int pos = tid + NT * q;
+            lv[q] = pos < nc ? sv[pos] : -INFINITY;
+            li[q] = pos < nc ? si[pos] : 0x7fffffff;
+        }
+        for (int round = 0; round < K; ++round) {
+            float bv = lv[0];
+            int bi = li[0];
+#pragma unroll
+            for (int q = 1; q < K; ++q)
+                if (better(lv[q], li[q], bv, bi)) { bv = lv[q]; bi = li[q]; }
+            float gv; int gi;
+            block_best(bv, bi, gv, gi);
+#pragma unroll
+            for (int q = 0; q < K; ++q)
+                if (li[q] == gi) { lv[q] = -INFINITY; li[q] = 0x7fffffff; }
+            if (tid == 0) {
                 top_v[(long long)row * K + round] = gv - lse;
                 top_i[(long long)row * K + round] = gi;
             }
+        }
+        return;
+    }
+    // ---- more than NT K elements tie with the threshold (constant rows): K rounds of arg-max over the whole row,
+    // each skipping the ids already emitted
+    __shared__ int taken[K];
+    for (int round = 0; round < K; ++round) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int v = tid; v < V; v += NT) {
+            bool skip = false;
+            for (int q = 0; q < round; ++q) skip |= taken[q] == v;
+            const float x = getx(v);
+            if (!skip && better(x, v, bv, bi)) { bv = x; bi = v; }
+        }
+        float gv; int gi;
+        block_best(bv, bi, gv, gi);
+        if (tid == 0) {
+            taken[round] = gi;
+            top_v[(long long)row * K + round] = gv - lse;
+            top_i[(long long)row * K + round] = gi;
         }
         __syncthreads();
     }

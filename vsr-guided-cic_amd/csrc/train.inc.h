@@ -203,7 +203,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         }
         {
             const size_t smem = (size_t)(A + c.R + 1 + 8 + c.R) * sizeof(float);
-            hipLaunchKernelGGL(k_attend, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
+            hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
                                c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
         }
         {   // S5
@@ -223,8 +223,9 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
             hipLaunchKernelGGL(k_lstm2_train, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
                                w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, c2o, B, H, h2n, c2n, g2);
             hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride_g, 256)), dim3(256), 0, s, gas, ns, stride_g, stride_g, ga);
-            hipLaunchKernelGGL(k_gatelogit, dim3(cdiv(B, 4)), dim3(256), 0, s, ga, 1, stride_g, hA, w.att_g_weight, c.zsum, (const float*)nullptr,
-                               slot, 1, c.L, B, A, logp_gates + (size_t)tt * 2, (long long)T * 2);
+            hipLaunchKernelGGL(k_gatelogit, dim3(cdiv(B, 4)), dim3(256), 0, s,
+                               GateLogitArgs{ga, 1, stride_g, hA, w.att_g_weight, c.zsum, nullptr, slot, 1, c.L, B, A,
+                                             logp_gates + (size_t)tt * 2, (long long)T * 2});
         }
         {   // S6
             GemmBuilder g;
@@ -235,10 +236,10 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
             g.a.p[0].slab_stride = stride;
             if (g.launch(s, h)) return fail("train S6 gemm launch failed");
             const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;
-            hipLaunchKernelGGL((k_vocab<1>), dim3(B), dim3(256), lds_row ? (size_t)V * sizeof(float) : 0, s, c.scratch, ns, stride,
+            hipLaunchKernelGGL((k_vocab<1, 256>), dim3(B), dim3(256), lds_row ? (size_t)V * sizeof(float) : 0, s, c.scratch, ns, stride,
                                w.out_fc_bias, B, V, (int)VM_FULL, c.top_v, c.top_i, logp_words + (size_t)tt * V, (long long)T * V,
                                (const int*)nullptr, (uint64_t)0, (uint32_t)tt, (const float*)nullptr, slot, 1, c.L, 0, h->vt_ptr, h->vt_ids,
-                               h->n_verbs, lds_row);
+                               h->n_verbs, lds_row, GateLogitArgs{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr, 0});
         }
         LAUNCHCHK();
     }

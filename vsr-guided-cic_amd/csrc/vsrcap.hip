@@ -58,6 +58,7 @@ struct Ctx {
     float* st[2][4];   // h1, c1, h2, c2 double-buffered
     int *slot[2], *word[2], *gate[2], *parent;
     float *s_t, *gpre, *g_t, *hA, *sa, *sent, *att, *zsum, *lg, *top_v;
+    float* ga_slabs;             // att_ga(g_t) partial sums: kept apart from `scratch`, the vocabulary GEMM overwrites that first
     int* top_i;
     float *seq[2], *mask[2];
     int *hist_parent, *hist_word, *hist_gate;
@@ -149,6 +150,7 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     c.att = b.take<float>(M * D);
     c.zsum = b.take<float>(M);
     c.lg = b.take<float>(M * 2);
+    c.ga_slabs = b.take<float>(M * A * 8);
     c.top_v = b.take<float>(M * KMAX);
     c.top_i = b.take<int>(M * KMAX);
     c.hist_parent = b.take<int>(T * M);
@@ -571,10 +573,13 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     // ---- attention
     {
         const size_t smem = (size_t)(A + c.R + 1 + 8 + c.R) * sizeof(float);
-        hipLaunchKernelGGL(k_attend, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+        if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out);
+        else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
                            io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out);
     }
     // ---- S5
+    GateLogitArgs gate_args;
     {
         GemmBuilder g;
         GemmProb& p0 = g.prob(M, 4 * H, c.scratch, 4 * H);
@@ -585,14 +590,15 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         GemmBuilder::seg(p1, c.g_t, H, nullptr, w.att_ga_weight, H, H);
         const int ns = g.finish(h);
         const long long stride = (long long)M * 4 * H, stride_g = (long long)M * A;
-        float* ga = c.scratch + stride * ns;
         g.a.p[0].slab_stride = stride;
-        g.a.p[1].C = ga; g.a.p[1].slab_stride = stride_g;
+        g.a.p[1].C = c.ga_slabs; g.a.p[1].slab_stride = stride_g;
         if (g.launch(s, h)) return fail("S5 gemm launch failed");
         hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
                            w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n);
-        hipLaunchKernelGGL(k_gatelogit, dim3(cdiv(M, 4)), dim3(256), 0, s, ga, ns, stride_g, c.hA, w.att_g_weight, c.zsum,
-                           io.verbs, io.slot, io.rpi, c.L, M, A, io.lg_out, io.lg_stride);
+        // the gate logits (z_g, log_softmax([z_g, zsum]), step :185-188) are nobody's input before the selection: they are
+        // computed by tail blocks of the vocabulary kernel's launch below instead of a launch of their own
+        gate_args = GateLogitArgs{c.ga_slabs, ns, stride_g, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A,
+                                  io.lg_out, io.lg_stride};
     }
     // ---- S6
     {
@@ -622,19 +628,25 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         c.pre1_ns = ns; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
         if (g.launch(s, h)) return fail("S6 gemm launch failed");
 #define VOCAB_ARGS c.scratch, ns, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
-                   io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row
+                   io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row, gate_args
         const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;          // combined logits row staged in LDS (<= 96 KB)
         const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
-        switch (io.K) {        // K = beam exactly: fewer insertion steps and merge rounds than rounding up to a power of two
-            case 1: hipLaunchKernelGGL((k_vocab<1>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
-            case 2: hipLaunchKernelGGL((k_vocab<2>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
-            case 3: hipLaunchKernelGGL((k_vocab<3>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
-            case 4: hipLaunchKernelGGL((k_vocab<4>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
-            case 5: hipLaunchKernelGGL((k_vocab<5>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
-            case 6: hipLaunchKernelGGL((k_vocab<6>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
-            case 7: hipLaunchKernelGGL((k_vocab<7>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
-            default: hipLaunchKernelGGL((k_vocab<8>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS); break;
+        // K = beam exactly (fewer selection rounds than rounding up to a power of two); 512 threads per row from V = 4096 up
+#define VOCAB_LAUNCH(KK)                                                                                              \
+    if (V >= 4096) hipLaunchKernelGGL((k_vocab<KK, 512>), dim3(M + cdiv(M, 8)), dim3(512), vsm, s, VOCAB_ARGS);                  \
+    else hipLaunchKernelGGL((k_vocab<KK, 256>), dim3(M + cdiv(M, 4)), dim3(256), vsm, s, VOCAB_ARGS);                            \
+    break;
+        switch (io.K) {
+            case 1: VOCAB_LAUNCH(1)
+            case 2: VOCAB_LAUNCH(2)
+            case 3: VOCAB_LAUNCH(3)
+            case 4: VOCAB_LAUNCH(4)
+            case 5: VOCAB_LAUNCH(5)
+            case 6: VOCAB_LAUNCH(6)
+            case 7: VOCAB_LAUNCH(7)
+            default: VOCAB_LAUNCH(8)
         }
+#undef VOCAB_LAUNCH
 #undef VOCAB_ARGS
     }
     LAUNCHCHK();
