@@ -520,8 +520,11 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
                                                const int* __restrict__ vt_ids, int n_verbs, int lds_row,
                                                const GateLogitArgs gate) {
     constexpr int NW = NT / 64;
-    if ((int)blockIdx.x >= M) {              // tail blocks: the gate logits of this step (independent of the vocabulary rows;
-        const int grow = ((int)blockIdx.x - M) * NW + (int)(threadIdx.x >> 6);      // they ride in this launch)
+    // the first ceil(gate.M / NW) blocks compute the gate logits of this step (independent of the vocabulary rows: they
+    // ride in this launch, and go first so that their short latency-bound loops run under the vocabulary rows)
+    const int gate_blocks = (gate.M + NW - 1) / NW;
+    if ((int)blockIdx.x < gate_blocks) {
+        const int grow = (int)blockIdx.x * NW + (int)(threadIdx.x >> 6);
         if (grow < gate.M) gatelogit_row(gate, grow, threadIdx.x & 63);
         return;
     }
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
     __shared__ int pick_s;
     extern __shared__ float lrow[];          // V floats when the launch passes dynamic LDS: the combined row is
     const bool use_lds = lds_row != 0;       // summed from the slabs ONCE and the later passes read it from LDS
-    const int row = blockIdx.x;
+    const int row = (int)blockIdx.x - gate_blocks;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = logits + (long long)row * V;
 
