@@ -191,6 +191,11 @@ int vsr_debug_copy(vsr_handle* h, const char* name, float* dst, size_t n_floats,
  * caller's stream.  end() synchronises the stream and returns the summed launch durations, the number of
  * launches and their ALGORITHMIC flops (2*M*N*K with the real, unpadded sizes). */
 int vsr_profile_begin(vsr_handle* h);
+/* the same, timing only every `every`-th GEMM launch: an event pair costs ~1 us of stream time, which a throughput
+ * measurement taken in the same region would otherwise pay on every launch.  vsr_profile_seen() = launches since begin;
+ * vsr_profile_end() then reports the timed launches only (their count, summed duration and flops). */
+int vsr_profile_begin_sampled(vsr_handle* h, int32_t every);
+int64_t vsr_profile_seen(const vsr_handle* h);
 int vsr_profile_end(vsr_handle* h, void* stream, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
 
 #ifdef __cplusplus

@@ -279,8 +279,16 @@ __global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__
 //   alpha    = softmax([z_sent ; z_det]) * mask ; alpha /= sum(alpha)
 //   att      = alpha_0 * sentinel + sum_r alpha_r * regions[img,slot,r,:]
 //   zsum     = sum_r mask_r * z_det[r]   (raw logits: the "shift" logit of the gate)
+// When g2.c2a is set the kernel first does the row's share of k_gate2 itself (sums of the S2 slabs -> g_t to global for
+// the next GEMM, hA to LDS and global, s_a and the sentinel to LDS only): one launch and one 8 KB round trip per row less.
+struct Gate2Args {
+    const float* c2a; const float* c2b; int nsplit; long long stride_a, stride_b;
+    const float* gpre; const float* c1n; const float* b_sfc; int H;
+    float* g_t; float* hA_out;
+};
+
 template <int NT>
-__global__ __launch_bounds__(NT) void k_attend(const float* __restrict__ hA, const float* __restrict__ sa,
+__global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* __restrict__ hA, const float* __restrict__ sa,
                                                 const float* __restrict__ sent, const float* __restrict__ P,
                                                 const float* __restrict__ regions, const float* __restrict__ rmask,
                                                 const int* __restrict__ ridx,
@@ -290,7 +298,9 @@ __global__ __launch_bounds__(NT) void k_attend(const float* __restrict__ hA, con
                                                 float* __restrict__ zsum, float* __restrict__ alpha_out) {
     extern __shared__ float sm[];
     float* hA_s = sm;             // A
-    float* z_s = sm + A;          // R + 1  (then alpha)
+    float* sa_s = hA_s + A;       // A   (fused gate2 only)
+    float* sent_s = sa_s + A;     // D   (fused gate2 only)
+    float* z_s = sent_s + D;      // R + 1  (then alpha)
     float* red = z_s + R + 1;     // 8
     int* ri_s = reinterpret_cast<int*>(red + 8);   // R: row of P / regions behind slot entry r (dense: its own row)
     const int row = xcd_item(M);
@@ -300,7 +310,31 @@ __global__ __launch_bounds__(NT) void k_attend(const float* __restrict__ hA, con
     const int img = row / rpi;
     const int k = slot ? slot[row] : fixed_slot;
     const long long sl = (long long)img * L + k;
-    for (int a = tid; a < A; a += NT) hA_s[a] = hA[(long long)row * A + a];
+    const bool fused = g2.c2a != nullptr;
+    if (fused) {
+        const int H = g2.H;
+        for (int c = tid; c < H + A; c += NT) {
+            float s = 0.f;
+            for (int q = 0; q < g2.nsplit; ++q) s += g2.c2a[q * g2.stride_a + (long long)row * (H + A) + c];
+            if (c < H) {
+                const long long o = (long long)row * H + c;
+                g2.g_t[o] = sigmoidf_(g2.gpre[o] + s) * tanhf(g2.c1n[o]);
+            } else {
+                hA_s[c - H] = s;
+                g2.hA_out[(long long)row * A + (c - H)] = s;
+            }
+        }
+        for (int cc = tid; cc < D + A; cc += NT) {
+            float s = 0.f;
+            for (int q = 0; q < g2.nsplit; ++q) s += g2.c2b[q * g2.stride_b + (long long)row * (D + A) + cc];
+            if (cc < D) sent_s[cc] = s + g2.b_sfc[cc];
+            else sa_s[cc - D] = s;
+        }
+    } else {
+        for (int a = tid; a < A; a += NT) hA_s[a] = hA[(long long)row * A + a];
+    }
+    const float* sa_row = fused ? sa_s : sa + (long long)row * A;
+    const float* srow = fused ? sent_s : sent + (long long)row * D;
     for (int r = tid; r < R; r += NT) {
         const int e = ridx ? ridx[sl * R + r] : (int)(sl * R + r);
         ri_s[r] = e < 0 ? 0 : e;                   // padding entries are masked and never dereferenced
@@ -317,7 +351,7 @@ __global__ __launch_bounds__(NT) void k_attend(const float* __restrict__ hA, con
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = r0 + NW * q;
-                const float* src = (r < R) ? P + (long long)ri_s[r] * A : sa + (long long)row * A;
+                const float* src = (r < R) ? P + (long long)ri_s[r] * A : sa_row;
                 // padding rows were never projected (att_va(0) = 0): their P entry is not defined, use the exact zero
                 const bool live = r < R + 1 && (r >= R || mk_row[r] != 0.f);
                 p[q] = live ? *reinterpret_cast<const float4*>(src + a) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -343,7 +377,6 @@ __global__ __launch_bounds__(NT) void k_attend(const float* __restrict__ hA, con
         }
     }
     // sentinel row-sum for its mask
-    const float* srow = sent + (long long)row * D;
     float ss = 0.f;
     for (int d = tid * 4; d < D; d += 4 * NT) {
         const float4 v = *reinterpret_cast<const float4*>(srow + d);

@@ -202,8 +202,8 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
                                B, H, A, D, g_t, hA, sent, sa, g1);
         }
         {
-            const size_t smem = (size_t)(A + c.R + 1 + 8 + c.R) * sizeof(float);
-            hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
+            const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
+            hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
                                c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
         }
         {   // S5

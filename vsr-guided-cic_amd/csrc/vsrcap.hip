@@ -96,6 +96,8 @@ struct vsr_handle {
     std::vector<hipEvent_t> ev;      // pool, pairs (start, stop)
     size_t ev_used = 0;
     double prof_flops = 0;
+    int prof_every = 1;              // time every prof_every-th GEMM launch (1 = all of them)
+    long long prof_seen = 0;         // GEMM launches since vsr_profile_begin*
 };
 
 // ---------------------------------------------------------------------------------------------- workspace
@@ -202,7 +204,7 @@ struct GemmBuilder {
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     dim3 grid(((a.G + 7) / 8) * 8), block(256);
-    const bool prof = h->profiling && h->ev_used + 2 <= h->ev.size();
+    const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
     if (big == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 1 && h->gemm_dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<2, 1>), grid, block, 0, s, a);
@@ -255,8 +257,16 @@ extern "C" void vsr_destroy(vsr_handle* h) {
     delete h;
 }
 
-extern "C" int vsr_profile_begin(vsr_handle* h) {
+extern "C" int vsr_profile_begin_sampled(vsr_handle* h, int32_t every);
+extern "C" int vsr_profile_begin(vsr_handle* h) { return vsr_profile_begin_sampled(h, 1); }
+
+extern "C" int64_t vsr_profile_seen(const vsr_handle* h) { return h ? (int64_t)h->prof_seen : 0; }
+
+extern "C" int vsr_profile_begin_sampled(vsr_handle* h, int32_t every) {
     if (!h) return fail("vsr_profile_begin: null handle");
+    if (every < 1) return fail("vsr_profile_begin_sampled: every must be >= 1");
+    h->prof_every = every;
+    h->prof_seen = 0;
     const size_t want = 2 * 4096;
     while (h->ev.size() < want) {
         hipEvent_t e;
@@ -566,16 +576,12 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[2].C = c2b_base; g.a.p[3].C = c2b_base + D;
         g.a.p[2].slab_stride = g.a.p[3].slab_stride = stride_b;
         if (g.launch(s, h)) return fail("S2 gemm launch failed");
-        const long long n = (long long)M * (H + A + D + A);
-        hipLaunchKernelGGL(k_gate2, dim3(cdiv(n, 256)), dim3(256), 0, s, c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n,
-                           w.s_fc_bias, M, H, A, D, c.g_t, c.hA, c.sent, c.sa, (float*)nullptr);
-    }
-    // ---- attention
-    {
-        const size_t smem = (size_t)(A + c.R + 1 + 8 + c.R) * sizeof(float);
-        if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+        // k_gate2's work (g_t, hA, s_a, sentinel from the S2 slabs) is done by the attention kernel's row blocks themselves
+        const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA};
+        const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
+        if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
                            io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out);
-        else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+        else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
                            io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out);
     }
     // ---- S5

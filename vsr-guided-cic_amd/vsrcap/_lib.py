@@ -66,6 +66,8 @@ SIGNATURES = {
     "vsr_train_backward": (I32, [P, P, P, C.POINTER(VsrWeights), P]),
     "vsr_debug_copy": (I32, [P, C.c_char_p, P, SZ, P]),
     "vsr_profile_begin": (I32, [P]),
+    "vsr_profile_begin_sampled": (I32, [P, I32]),
+    "vsr_profile_seen": (I64, [P]),
     "vsr_profile_end": (I32, [P, P, C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double)]),
     "vsr_step": (I32, [P, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P]),
 }

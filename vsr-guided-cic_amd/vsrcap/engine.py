@@ -211,8 +211,12 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ measurement
-    def profile_begin(self):
-        _lib.check(self.lib.vsr_profile_begin(self.h))
+    def profile_begin(self, every=1):
+        """HIP events around every `every`-th GEMM launch from now on (1 = all)."""
+        _lib.check(self.lib.vsr_profile_begin_sampled(self.h, int(every)))
+
+    def profile_seen(self):
+        return int(self.lib.vsr_profile_seen(self.h))
 
     def profile_end(self, device):
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
