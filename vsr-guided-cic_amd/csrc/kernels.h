@@ -34,30 +34,23 @@ __device__ __forceinline__ int xcd_item(int n) {
 
 // ---------------------------------------------------------------------------------------------- prepare
 // pooled descriptor vbar[b] = sum_r det[b,r,:] / #(rows with non-zero sum)           (step :126-128)
-// row_img (optional): decoder row b pools the detections of image row_img[b] (several captions of one image)
-__global__ __launch_bounds__(256) void k_pool(const float* __restrict__ det, const int* __restrict__ row_img, int R0, int D,
-                                              float* __restrict__ vbar) {
-    __shared__ float cnt_s[4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* X = det + (long long)(row_img ? row_img[b] : b) * R0 * D;
-    float cnt = 0.f;
-    for (int r = wave; r < R0; r += 4) {
-        float s = 0.f;
-        for (int d = lane * 4; d < D; d += 256) {
-            float4 v = *reinterpret_cast<const float4*>(X + (long long)r * D + d);
-            s += (v.x + v.y) + (v.z + v.w);
-        }
-        s = wave_sum(s);
-        cnt += (s != 0.f) ? 1.f : 0.f;
+// dmask = k_rowmask over the (n_img * R0) detection rows; one block per (decoder row, 1024-column chunk), rows summed in
+// order r = 0..R0-1.  row_img (optional): decoder row b pools the detections of image row_img[b].
+__global__ __launch_bounds__(256) void k_pool(const float* __restrict__ det, const int* __restrict__ row_img,
+                                              const float* __restrict__ dmask, int R0, int D, float* __restrict__ vbar) {
+    const int b = blockIdx.x, d = (blockIdx.y * 256 + threadIdx.x) * 4;
+    const int img = row_img ? row_img[b] : b;
+    const float* X = det + (long long)img * R0 * D;
+    const float* mk = dmask + (long long)img * R0;
+    float n = 0.f;
+    for (int r = 0; r < R0; ++r) n += mk[r];
+    if (d >= D) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < R0; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(X + (long long)r * D + d);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    if (lane == 0) cnt_s[wave] = cnt;
-    __syncthreads();
-    const float n = (cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]);
-    for (int d = tid; d < D; d += 256) {
-        float s = 0.f;
-        for (int r = 0; r < R0; ++r) s += X[(long long)r * D + d];
-        vbar[(long long)b * D + d] = s / n;
-    }
+    *reinterpret_cast<float4*>(vbar + (long long)b * D + d) = make_float4(s.x / n, s.y / n, s.z / n, s.w / n);
 }
 
 // region-row masks m[row] = (sum_d regions[row,:] != 0), one wave per row                 (step :159)
@@ -190,6 +183,12 @@ __global__ void k_slab_reduce(const float* __restrict__ slabs, int nsplit, long 
     float s = 0.f;
     for (int k = 0; k < nsplit; ++k) s += slabs[k * stride + i];
     out[i] = s;
+}
+
+// decode state at t = 0: slot pointer 0, previous word = bos (init_state :109-115; the h/c states are one memset)
+__global__ void k_init_rows(int* __restrict__ slot, int* __restrict__ word, int bos, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { slot[i] = 0; word[i] = bos; }
 }
 
 __global__ void k_fill_i32(int* p, int v, int n) {

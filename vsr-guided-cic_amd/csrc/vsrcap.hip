@@ -52,6 +52,7 @@ struct Ctx {
     const int* ridx = nullptr;   // (B, L, R) absolute bank row per slot entry (index-list format) or null
     int* ridx_buf = nullptr;
     float* bmask = nullptr;      // row masks of the rows att_va runs over (dense: = rmask)
+    float* dmask = nullptr;      // row masks of the detection rows (pooled descriptor)
     float *vbar, *vproj, *vproj2, *P, *rmask;
     int *vlist, *nvalid_dev;     // non-padding region rows (ascending) and their number
     int nvalid = 0;
@@ -93,6 +94,8 @@ struct vsr_handle {
     Ctx c;
     // measurement
     bool profiling = false;
+    hipEvent_t ev_count = nullptr;   // prepare(): the row count has reached the host
+    int* host_back = nullptr;        // pinned landing place of that read-back (2 ints)
     std::vector<hipEvent_t> ev;      // pool, pairs (start, stop)
     size_t ev_used = 0;
     double prof_flops = 0;
@@ -131,6 +134,7 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
         c.bmask = c.rmask;
         c.ridx_buf = nullptr;
     }
+    c.dmask = b.take<float>((size_t)(c.Rb > 0 ? c.n_img : B) * c.R0);
     c.vlist = b.take<int>(prows);
     c.nvalid_dev = b.take<int>(4);
     for (int i = 0; i < 2; ++i)
@@ -253,6 +257,8 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
 extern "C" void vsr_destroy(vsr_handle* h) {
     if (!h) return;
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->ev_count) (void)hipEventDestroy(h->ev_count);
+    if (h->host_back) (void)hipHostFree(h->host_back);
     free_train_ctx(h->tc);
     delete h;
 }
@@ -394,8 +400,10 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     h->prepared = false;
     invalidate_train_ctx(h->tc);       // a saved forward refers to the hoisted tensors of the previous prepare()
 
-    // pooled descriptor and region-row masks
-    hipLaunchKernelGGL(k_pool, dim3(B), dim3(256), 0, s, det, indexed ? row_img : nullptr, R0, D, c.vbar);
+    // region-row masks, then the list of NON-PADDING rows att_va has to run over (att_va(0) = 0).  Their count has to
+    // reach the host to size that launch: the one place where this library waits, and it waits for an EVENT behind the
+    // copy, with the pooled descriptor and its projections queued after it, so the GPU has work while the host wakes up.
+    // (The index-list format reports its out-of-range count through the same read-back.)
     const long long rows = (long long)B * L * R;                         // slot entries
     const long long prows = indexed ? (long long)n_img * Rb : rows;      // rows att_va runs over
     hipLaunchKernelGGL(k_rowmask, dim3(cdiv(prows, 4)), dim3(256), 0, s, regions, prows, D, c.bmask);
@@ -404,6 +412,18 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
         hipLaunchKernelGGL(k_index_rows, dim3(cdiv(rows, 256)), dim3(256), 0, s, slot_idx, row_img, c.bmask, B, L * R, Rb, n_img,
                            c.ridx_buf, c.rmask, c.nvalid_dev + 1);
     }
+    hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, s, c.bmask, (int)prows, c.vlist, c.nvalid_dev);
+    LAUNCHCHK();
+    if (!h->host_back) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->host_back), 2 * sizeof(int), hipHostMallocDefault));
+    int* back = h->host_back;                                            // pinned: the copy does not block this thread
+    HIPCHK(hipMemcpyAsync(back, c.nvalid_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (!h->ev_count) HIPCHK(hipEventCreateWithFlags(&h->ev_count, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->ev_count, s));
+
+    // pooled descriptor
+    const long long drows = (long long)(indexed ? n_img : B) * R0;
+    hipLaunchKernelGGL(k_rowmask, dim3(cdiv(drows, 4)), dim3(256), 0, s, det, drows, D, c.dmask);
+    hipLaunchKernelGGL(k_pool, dim3(B, cdiv(D, 1024)), dim3(256), 0, s, det, indexed ? row_img : nullptr, c.dmask, R0, D, c.vbar);
     LAUNCHCHK();
 
     // hoisted vbar projections: columns [voff, voff + D) of the LSTM1 / gate input weights
@@ -438,13 +458,7 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
         hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.vproj2);
         LAUNCHCHK();
     }
-    // att_va over the NON-PADDING rows only (att_va(0) = 0): compact row list, gathered GEMM, scatter back.
-    // The row count has to reach the host to size the launch: the one place where this library waits for the stream
-    // (the index-list format reports its out-of-range count through the same read-back).
-    hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, s, c.bmask, (int)prows, c.vlist, c.nvalid_dev);
-    int back[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(back, c.nvalid_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipEventSynchronize(h->ev_count));
     c.nvalid = back[0];
     if (indexed && back[1] != 0) return fail("%s: %d slot entries index outside the feature bank [-1, %d) or name an image outside [0, %d)", who, back[1], Rb, n_img);
     if (c.nvalid > 0) {
@@ -669,9 +683,9 @@ static int check_ready(vsr_handle* h, const char* who) {
 static int zero_state(vsr_handle* h, int M, hipStream_t s) {
     Ctx& c = h->c;
     const size_t n = (size_t)M * h->d.rnn_size * sizeof(float);
-    for (int j = 0; j < 4; ++j) HIPCHK(hipMemsetAsync(c.st[0][j], 0, n, s));
-    HIPCHK(hipMemsetAsync(c.slot[0], 0, (size_t)M * sizeof(int), s));
-    hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, c.word[0], h->d.bos_idx, M);
+    // the four state arrays of buffer 0 are consecutive in the workspace (carve): one memset
+    HIPCHK(hipMemsetAsync(c.st[0][0], 0, (size_t)(reinterpret_cast<char*>(c.st[0][3]) - reinterpret_cast<char*>(c.st[0][0])) + n, s));
+    hipLaunchKernelGGL(k_init_rows, dim3(cdiv(M, 256)), dim3(256), 0, s, c.slot[0], c.word[0], h->d.bos_idx, M);
     LAUNCHCHK();
     return 0;
 }
