@@ -203,7 +203,9 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         }
         {
             const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
-            hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
+            if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
+                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
+            else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
                                c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
         }
         {   // S5
@@ -368,18 +370,25 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             g.a.p[2].C = C2; g.a.p[2].slab_stride = st2;
             if (g.launch(s, h)) return fail("bwd gemm 1 launch failed");
         }
-        hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)B * D, 256)), dim3(256), 0, s, C0, ns1, st0, H + D, H, D, B, (const float*)nullptr, t.datt);
-        hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, C2, ns1, st2, H, 0, H, B, (const float*)nullptr, t.dg_t);
-        // dh1 so far = dh1_a + carry   (into dh_tot)
-        hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, C0, ns1, st0, H + D, 0, H, B, (const float*)t.dh1_c, t.dh_tot);
-        // new dh2 carry (hh part; the LSTM1-input part is added after GEMM 3)
-        hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, C1, ns1, st1, H, 0, H, B, (const float*)nullptr, t.dh2_c);
+        {   // datt, dg_t, dh1 so far (= dh1_a + carry, into dh_tot) and the new dh2 carry (hh part; the LSTM1-input part is
+            // added after GEMM 3): one launch
+            SlabJobs jb;
+            jb.rows = B;
+            jb.j[0] = SlabJob{C0, ns1, st0, H + D, H, D, nullptr, t.datt};
+            jb.j[1] = SlabJob{C2, ns1, st2, H, 0, H, nullptr, t.dg_t};
+            jb.j[2] = SlabJob{C0, ns1, st0, H + D, 0, H, t.dh1_c, t.dh_tot};
+            jb.j[3] = SlabJob{C1, ns1, st1, H, 0, H, nullptr, t.dh2_c};
+            const int wmax = D > H ? D : H;
+            hipLaunchKernelGGL(k_slab_cols_multi, dim3(cdiv((long long)B * wmax, 256), 4), dim3(256), 0, s, jb);
+        }
         // attention
         {
             const size_t smem = (size_t)(R1 + 8) * sizeof(float);
             hipLaunchKernelGGL(k_dalpha, dim3(cdiv((long long)B * R1, 4)), dim3(256), 0, s, t.datt, sent, c.regions, c.rmask, slot, B, c.L, c.R, D,
                                t.dalpha);
-            hipLaunchKernelGGL(k_attend_bwd, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask,
+            if (A >= 512) hipLaunchKernelGGL(k_attend_bwd<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask,
+                               slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws);
+            else hipLaunchKernelGGL(k_attend_bwd<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask,
                                slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws);
         }
         // shift gate: dq into dpre1[:, 5H:6H], dtc
@@ -400,8 +409,11 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             g.a.p[0].C = Ca; g.a.p[0].slab_stride = st;
             g.a.p[1].C = Cb; g.a.p[1].slab_stride = st;
             if (g.launch(s, h)) return fail("bwd gemm 2 launch failed");
-            hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, Ca, ns, st, H, 0, H, B, (const float*)t.dh_tot, t.dh_tot);
-            hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, Cb, ns, st, H, 0, H, B, (const float*)nullptr, t.ds_t);
+            SlabJobs jb;
+            jb.rows = B;
+            jb.j[0] = SlabJob{Ca, ns, st, H, 0, H, t.dh_tot, t.dh_tot};
+            jb.j[1] = SlabJob{Cb, ns, st, H, 0, H, nullptr, t.ds_t};
+            hipLaunchKernelGGL(k_slab_cols_multi, dim3(cdiv((long long)BH, 256), 2), dim3(256), 0, s, jb);
         }
         // sentinel gate and LSTM1
         hipLaunchKernelGGL(k_sgate_bwd, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.ds_t, g1, (long long)6 * H, c1, B, H, dpre1 + 4 * H,
@@ -425,10 +437,11 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             g.a.p[0].C = t.scratch; g.a.p[0].slab_stride = st;
             if (d.h2_first_lstm) { g.a.p[1].C = t.scratch + st * ns; g.a.p[1].slab_stride = st; }
             if (g.launch(s, h)) return fail("bwd gemm 3 launch failed");
-            hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.scratch, ns, st, H, 0, H, B, (const float*)nullptr, t.dh1_c);
-            if (d.h2_first_lstm)
-                hipLaunchKernelGGL(k_slab_cols, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.scratch + st * ns, ns, st, H, 0, H, B,
-                                   (const float*)t.dh2_c, t.dh2_c);
+            SlabJobs jb;
+            jb.rows = B;
+            jb.j[0] = SlabJob{t.scratch, ns, st, H, 0, H, nullptr, t.dh1_c};
+            jb.j[1] = SlabJob{t.scratch + st * ns, ns, st, H, 0, H, t.dh2_c, t.dh2_c};
+            hipLaunchKernelGGL(k_slab_cols_multi, dim3(cdiv((long long)BH, 256), d.h2_first_lstm ? 2 : 1), dim3(256), 0, s, jb);
         }
         LAUNCHCHK();
     }

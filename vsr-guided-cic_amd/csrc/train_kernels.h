@@ -251,7 +251,8 @@ __global__ __launch_bounds__(256) void k_dalpha(const float* __restrict__ datt, 
 //   z_r = w_a . tanh(P_r + hA) ;  z_0 = w_s . tanh(sa + hA)
 // in : datt (M,D), dzsum (M), alpha (M,R+1), saved hA, sa, sent; P, X, rmask of the row's (image, slot)
 // out: dsent (M,D) = a0 * datt; dsa (M,A); dhA (M,A) += ; dP[(image,slot)] (R,A) += ; per-row partials of dw_a, dw_s
-__global__ __launch_bounds__(256) void k_attend_bwd(const float* __restrict__ datt, const float* __restrict__ dalpha_in,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_attend_bwd(const float* __restrict__ datt, const float* __restrict__ dalpha_in,
                                                     const float* __restrict__ dzsum,
                                                     const float* __restrict__ alpha, const float* __restrict__ hA,
                                                     const float* __restrict__ sa, const float* __restrict__ sent,
@@ -274,10 +275,10 @@ __global__ __launch_bounds__(256) void k_attend_bwd(const float* __restrict__ da
     const float* al = alpha + (long long)row * (R + 1);
     const float* mk = rmask + sl * R;
     // dalpha comes from k_dalpha (one wave per (row, j))
-    for (int j = tid; j < R + 1; j += 256) da[j] = dalpha_in[(long long)row * (R + 1) + j];
+    for (int j = tid; j < R + 1; j += NT) da[j] = dalpha_in[(long long)row * (R + 1) + j];
     // dsent = alpha_0 * datt
     const float a0 = al[0];
-    for (int d = tid * 4; d < D; d += 1024) {
+    for (int d = tid * 4; d < D; d += 4 * NT) {
         const float4 a = *reinterpret_cast<const float4*>(g + d);
         *reinterpret_cast<float4*>(dsent + (long long)row * D + d) = make_float4(a0 * a.x, a0 * a.y, a0 * a.z, a0 * a.w);
     }
@@ -303,18 +304,34 @@ __global__ __launch_bounds__(256) void k_attend_bwd(const float* __restrict__ da
     // du = dz * w * (1 - tanh^2(P + hA)); dP rows, dhA, dsa and the per-row partials of dw_a / dw_s
     const float* Pk = P + sl * R * A;
     float* dPk = dP + sl * R * A;
-    for (int a = tid; a < A; a += 256) {
+    for (int a = tid; a < A; a += NT) {
         const float h = hA[(long long)row * A + a];
         const float wa = w_a[a];
         float dh = 0.f, dwa = 0.f;
-        for (int r = 0; r < R; ++r) {
-            const float dz = da[r + 1];
-            if (dz != 0.f) {
-                const float th = tanhf(Pk[(long long)r * A + a] + h);
-                const float du = dz * wa * (1.f - th * th);
-                dPk[(long long)r * A + a] += du;           // a row visits its slots one step at a time: no race
-                dh += du;
-                dwa += dz * th;
+        // eight region rows per round: their P and dP loads are all in flight before the first tanh (the row loop was one
+        // dependent load -> tanh -> read-modify-write per row: 36 serial L2 round trips)
+        for (int r0 = 0; r0 < R; r0 += 8) {
+            float pv[8], dpv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + q;
+                const bool live = r < R && da[r + 1] != 0.f;            // uniform over the workgroup
+                pv[q] = live ? Pk[(long long)r * A + a] : 0.f;
+                dpv[q] = live ? dPk[(long long)r * A + a] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + q;
+                if (r < R) {
+                    const float dz = da[r + 1];
+                    if (dz != 0.f) {
+                        const float th = tanhf(pv[q] + h);
+                        const float du = dz * wa * (1.f - th * th);
+                        dPk[(long long)r * A + a] = dpv[q] + du;           // a row visits its slots one step at a time: no race
+                        dh += du;
+                        dwa += dz * th;
+                    }
+                }
             }
         }
         const float ths = tanhf(sa[(long long)row * A + a] + h);
@@ -360,6 +377,20 @@ __global__ void k_add3(const float* __restrict__ a, const float* __restrict__ b,
 }
 
 // strided variant for slab sums: out[r][c] = sum_k slabs[k][r][c0 + c] (+ add[r][c])
+// up to four k_slab_cols jobs of one backward step in one launch (grid.y = job): out = (add ? add : 0) + sum of the slabs'
+// column window [c0, c0 + w)
+struct SlabJob { const float* slabs; int nslab; long long stride; int ld, c0, w; const float* add; float* out; };
+struct SlabJobs { SlabJob j[4]; int rows; };
+__global__ void k_slab_cols_multi(const SlabJobs jobs) {
+    const SlabJob& q = jobs.j[blockIdx.y];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)jobs.rows * q.w) return;
+    const int r = (int)(i / q.w), c = (int)(i % q.w);
+    float s = q.add ? q.add[i] : 0.f;
+    for (int k = 0; k < q.nslab; ++k) s += q.slabs[k * q.stride + (long long)r * q.ld + q.c0 + c];
+    q.out[i] = s;
+}
+
 __global__ void k_slab_cols(const float* __restrict__ slabs, int nslab, long long stride, int ld, int c0, int w, int rows,
                             const float* __restrict__ add, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
