@@ -19,7 +19,7 @@ struct TrainCtx {
     const float* logp_g = nullptr;     // (B,T,2)
     float *h1s, *c1s, *h2s, *c2s;      // (T+1, B, H): slot 0 = zeros
     float *gates1, *gates2, *s_ts, *g_ts, *hAs, *sas, *gas, *sents, *atts, *alphas, *x_all;
-    int *word32, *slot32;
+    int *word32, *slot32, *rows_bt;
     float *dlogits, *dh2_voc, *dpre1, *dpre2, *dhA_all, *dsent_all, *dsa_all, *dga_all, *dwa_rows, *dws_rows, *dwg_rows, *dP;
     float *dalpha;
     float *datt, *dg_t, *dtc, *ds_t, *dh_tot, *dzsum, *dh1_c, *dh2_c, *dc1_c[2], *dc2_c[2], *dpre1sum, *dpre2sum, *dx_all;
@@ -49,7 +49,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.hAs = b.take<float>(TB * A); t.sas = b.take<float>(TB * A); t.gas = b.take<float>(TB * A);
     t.sents = b.take<float>(TB * D); t.atts = b.take<float>(TB * D); t.alphas = b.take<float>(TB * R1);
     t.x_all = b.take<float>(TB * E);
-    t.word32 = b.take<int>(TB); t.slot32 = b.take<int>(TB);
+    t.word32 = b.take<int>(TB); t.slot32 = b.take<int>(TB); t.rows_bt = b.take<int>(TB);
     t.dlogits = b.take<float>(TB * up4(V)); t.dh2_voc = b.take<float>(TB * H);
     t.dpre1 = b.take<float>(TB * 6 * H); t.dpre2 = b.take<float>(TB * 4 * H);
     t.dhA_all = b.take<float>(TB * A); t.dsent_all = b.take<float>(TB * D); t.dsa_all = b.take<float>(TB * A); t.dga_all = b.take<float>(TB * A);
@@ -77,7 +77,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.tpad_begin = base ? base + tp0 : nullptr;
     t.tpad_bytes = b.off - tp0;
     // GEMM slab scratch: 8 slabs of the largest product of the training path
-    size_t big = std::max({4 * H * in1, V * H, 4 * H * in2, A * D, TB * H, TB * E, D * H, B * (in2 + 2 * H), H * in1});
+    size_t big = std::max({4 * H * in1, V * H, 4 * H * in2, A * D, TB * H, TB * E, D * H, B * (in2 + 2 * H), H * in1, TB * V});
     t.scratch_floats = big * 8;
     t.scratch = b.take<float>(t.scratch_floats);
     return (b.off + 255) & ~size_t(255);
@@ -144,11 +144,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     HIPCHK(hipMemsetAsync(t.c1s, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.h2s, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.c2s, 0, BH * sizeof(float), s));
-    for (int tt = 0; tt < T; ++tt) {
-        hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, word_in + tt, (long long)T, t.word32 + (size_t)tt * B, B);
-        if (slots) hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, slots + tt, (long long)T, t.slot32 + (size_t)tt * B, B);
-        else hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, t.slot32 + (size_t)tt * B, tt, B);
-    }
+    hipLaunchKernelGGL(k_train_indices, dim3(cdiv(TB, 256)), dim3(256), 0, s, word_in, slots, T, B, t.word32, t.slot32, t.rows_bt);
     hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((long long)TB * E, 256)), dim3(256), 0, s, w.embed_weight, t.word32, TB, E, t.x_all);
     LAUNCHCHK();
 
@@ -229,20 +225,26 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
                                GateLogitArgs{ga, 1, stride_g, hA, w.att_g_weight, c.zsum, nullptr, slot, 1, c.L, B, A,
                                              logp_gates + (size_t)tt * 2, (long long)T * 2});
         }
-        {   // S6
-            GemmBuilder g;
-            GemmProb& p0 = g.prob(B, V, c.scratch, V);
-            GemmBuilder::seg(p0, h2n, H, nullptr, w.out_fc_weight, H, H);
-            const int ns = g.finish(h);
-            const long long stride = (long long)B * V;
-            g.a.p[0].slab_stride = stride;
-            if (g.launch(s, h)) return fail("train S6 gemm launch failed");
-            const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;
-            hipLaunchKernelGGL((k_vocab<1, 256>), dim3(B), dim3(256), lds_row ? (size_t)V * sizeof(float) : 0, s, c.scratch, ns, stride,
-                               w.out_fc_bias, B, V, (int)VM_FULL, c.top_v, c.top_i, logp_words + (size_t)tt * V, (long long)T * V,
-                               (const int*)nullptr, (uint64_t)0, (uint32_t)tt, (const float*)nullptr, slot, 1, c.L, 0, h->vt_ptr, h->vt_ids,
-                               h->n_verbs, lds_row, GateLogitArgs{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr, 0});
-        }
+        LAUNCHCHK();
+    }
+    {   // S6 for all steps at once: logits = h2[(b, t)] . out_fc^T (M = T B rows gathered in (b, t) order, so that the
+        // (B, T, V) log-prob tensor is written row by row), then one log_softmax launch
+        GemmBuilder g;
+        GemmProb& p0 = g.prob(TB, V, t.scratch, V);
+        GemmBuilder::seg(p0, t.h2s, H, t.rows_bt, w.out_fc_weight, H, H);
+        const int ns = g.finish(h);
+        const long long stride = (long long)TB * V;
+        if ((size_t)stride * ns > t.scratch_floats) return fail("training scratch too small for the vocabulary projection (%lld x %d)", stride, ns);
+        g.a.p[0].slab_stride = stride;
+        if (g.launch(s, h)) return fail("train S6 gemm launch failed");
+        const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;
+        const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
+        const GateLogitArgs no_gate{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr, 0};
+#define TRAIN_VOCAB_ARGS t.scratch, ns, stride, w.out_fc_bias, TB, V, (int)VM_FULL, c.top_v, c.top_i, logp_words, (long long)V, (const int*)nullptr, \
+                         (uint64_t)0, (uint32_t)0, (const float*)nullptr, (const int*)nullptr, 1, c.L, 0, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row, no_gate
+        if (V >= 4096) hipLaunchKernelGGL((k_vocab<1, 512>), dim3(TB), dim3(512), vsm, s, TRAIN_VOCAB_ARGS);
+        else hipLaunchKernelGGL((k_vocab<1, 256>), dim3(TB), dim3(256), vsm, s, TRAIN_VOCAB_ARGS);
+#undef TRAIN_VOCAB_ARGS
         LAUNCHCHK();
     }
     t.logp_w = logp_words;

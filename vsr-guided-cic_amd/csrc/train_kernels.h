@@ -377,6 +377,18 @@ __global__ void k_add3(const float* __restrict__ a, const float* __restrict__ b,
 }
 
 // strided variant for slab sums: out[r][c] = sum_k slabs[k][r][c0 + c] (+ add[r][c])
+// (B, T) int64 captions / slot traces -> (T, B) int32 step-major copies, plus the (b, t)-ordered row list of the saved
+// states (row (t + 1) * B + b) that the batched vocabulary projection gathers through.  slots == null: slot = step.
+__global__ void k_train_indices(const int64_t* __restrict__ word_in, const int64_t* __restrict__ slots, int T, int B,
+                                int* __restrict__ word32, int* __restrict__ slot32, int* __restrict__ rows_bt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * B) return;
+    const int tt = i / B, b = i - tt * B;
+    word32[i] = (int)word_in[(long long)b * T + tt];
+    slot32[i] = slots ? (int)slots[(long long)b * T + tt] : tt;
+    rows_bt[b * T + tt] = (tt + 1) * B + b;
+}
+
 // up to four k_slab_cols jobs of one backward step in one launch (grid.y = job): out = (add ? add : 0) + sum of the slabs'
 // column window [c0, c0 + w)
 struct SlabJob { const float* slabs; int nslab; long long stride; int ld, c0, w; const float* add; float* out; };
