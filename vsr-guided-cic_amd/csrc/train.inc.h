@@ -26,6 +26,7 @@ struct TrainCtx {
     float *wT_ih1, *wT_is, *wT_ig, *wT_hh1, *wT_hs, *wT_ih2, *wT_hh2, *wT_hg, *wT_ha, *wT_sfc, *wT_sa, *wT_ga, *wT_out;
     float *tX_h2prev, *tX_x, *tX_h1prev, *tX_h1, *tX_att, *tX_st, *tX_gt, *tX_h2, *tX_vbar, *tX_reg;
     float *tY_dpre1, *tY_dpre2, *tY_dlogits, *tY_dhA, *tY_dsent, *tY_dsa, *tY_dga, *tY_dpre1sum, *tY_dpre2sum, *tY_dP;
+    float* xproj_all;            // (T B, 6H): embedding rows through the x columns of the LSTM1 / gate input weights
     float* scratch;
     size_t scratch_floats = 0;
     char* tpad_begin = nullptr;        // transposed-activation region (zeroed when its rows are padded)
@@ -59,7 +60,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.dh_tot = b.take<float>(B * H); t.dzsum = b.take<float>(B); t.dalpha = b.take<float>(B * R1);
     t.dh1_c = b.take<float>(B * H); t.dh2_c = b.take<float>(B * H);
     for (int i = 0; i < 2; ++i) { t.dc1_c[i] = b.take<float>(B * H); t.dc2_c[i] = b.take<float>(B * H); }
-    t.dpre1sum = b.take<float>(B * 6 * H); t.dpre2sum = b.take<float>(B * 4 * H); t.dx_all = b.take<float>(TB * E);
+    t.dpre1sum = b.take<float>(B * 6 * H); t.dpre2sum = b.take<float>(B * 4 * H); t.dx_all = b.take<float>(TB * E); t.xproj_all = b.take<float>(TB * 6 * H);
     t.wT_ih1 = b.take<float>(in1 * 4 * H); t.wT_is = b.take<float>(in1 * H); t.wT_ig = b.take<float>(in1 * H);
     t.wT_hh1 = b.take<float>(H * 4 * H); t.wT_hs = b.take<float>(H * H);
     t.wT_ih2 = b.take<float>(in2 * 4 * H); t.wT_hh2 = b.take<float>(H * 4 * H);
@@ -77,7 +78,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.tpad_begin = base ? base + tp0 : nullptr;
     t.tpad_bytes = b.off - tp0;
     // GEMM slab scratch: 8 slabs of the largest product of the training path
-    size_t big = std::max({4 * H * in1, V * H, 4 * H * in2, A * D, TB * H, TB * E, D * H, B * (in2 + 2 * H), H * in1, TB * V});
+    size_t big = std::max({4 * H * in1, V * H, 4 * H * in2, A * D, TB * H, TB * E, D * H, B * (in2 + 2 * H), H * in1, TB * V, TB * 6 * H});
     t.scratch_floats = big * 8;
     t.scratch = b.take<float>(t.scratch_floats);
     return (b.off + 255) & ~size_t(255);
@@ -147,6 +148,22 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     hipLaunchKernelGGL(k_train_indices, dim3(cdiv(TB, 256)), dim3(256), 0, s, word_in, slots, T, B, t.word32, t.slot32, t.rows_bt);
     hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((long long)TB * E, 256)), dim3(256), 0, s, w.embed_weight, t.word32, TB, E, t.x_all);
     LAUNCHCHK();
+    {   // the x part of every step's LSTM1 / gate pre-activations does not depend on the recurrence: one GEMM with M = T B
+        GemmBuilder g;
+        const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
+        const int Nn[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
+        for (int i = 0; i < 3; ++i) {
+            GemmProb& p = g.prob(TB, Nn[i], t.scratch + off[i], 6 * H);
+            GemmBuilder::seg(p, t.x_all, E, nullptr, Wih[i] + xoff, in1, E);
+        }
+        const int ns = g.finish(h);
+        const long long stride = (long long)TB * 6 * H;
+        if ((size_t)stride * ns > t.scratch_floats) return fail("training scratch too small for the x projection (%lld x %d)", stride, ns);
+        for (int i = 0; i < 3; ++i) g.a.p[i].slab_stride = stride;
+        if (g.launch(s, h)) return fail("train x-projection gemm launch failed");
+        hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, t.scratch, ns, stride, stride, t.xproj_all);
+        LAUNCHCHK();
+    }
 
     for (int tt = 0; tt < T; ++tt) {
         const float *h1o = t.h1s + (size_t)tt * BH, *c1o = t.c1s + (size_t)tt * BH, *h2o = t.h2s + (size_t)tt * BH, *c2o = t.c2s + (size_t)tt * BH;
@@ -158,23 +175,27 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         float *sent = t.sents + (size_t)tt * B * D, *att = t.atts + (size_t)tt * B * D, *alpha = t.alphas + (size_t)tt * B * (c.R + 1);
         const float* x = t.x_all + (size_t)tt * B * E;
         const int* slot = t.slot32 + (size_t)tt * B;
-        {   // S1
-            GemmBuilder g;
-            const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
-            const float* Whh[3] = {w.lstm1_weight_hh, w.W1_hs_weight, nullptr};
-            const int Nn[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
-            for (int i = 0; i < 3; ++i) {
-                GemmProb& p = g.prob(B, Nn[i], c.scratch + off[i], 6 * H);
-                if (d.h2_first_lstm && tt > 0) GemmBuilder::seg(p, h2o, H, nullptr, Wih[i], in1, H);
-                GemmBuilder::seg(p, x, E, nullptr, Wih[i] + xoff, in1, E);
-                if (Whh[i] && tt > 0) GemmBuilder::seg(p, h1o, H, nullptr, Whh[i], H, H);
-            }
-            const int ns = g.finish(h);
+        {   // S1: the recurrent parts only (h2, h1 of the previous step); nothing to multiply at step 0
+            int ns = 0;
             const long long stride = (long long)B * 6 * H;
-            for (int i = 0; i < 3; ++i) g.a.p[i].slab_stride = stride;
-            if (g.launch(s, h)) return fail("train S1 gemm launch failed");
-            hipLaunchKernelGGL(k_lstm1_train, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj, c1o, B, H,
-                               h1n, c1n, s_t, c.gpre, g1);
+            if (tt > 0) {
+                GemmBuilder g;
+                const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
+                const float* Whh[3] = {w.lstm1_weight_hh, w.W1_hs_weight, nullptr};
+                const int Nn[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
+                for (int i = 0; i < 3; ++i) {
+                    if (!d.h2_first_lstm && !Whh[i]) continue;
+                    GemmProb& p = g.prob(B, Nn[i], c.scratch + off[i], 6 * H);
+                    if (d.h2_first_lstm) GemmBuilder::seg(p, h2o, H, nullptr, Wih[i], in1, H);
+                    if (Whh[i]) GemmBuilder::seg(p, h1o, H, nullptr, Whh[i], H, H);
+                }
+                ns = g.finish(h);
+                for (int i = 0; i < g.a.nprob; ++i) g.a.p[i].slab_stride = stride;
+                if (g.launch(s, h)) return fail("train S1 gemm launch failed");
+            }
+            hipLaunchKernelGGL(k_lstm1_train, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj,
+                               t.xproj_all + (size_t)tt * B * 6 * H, c1o, B, H, h1n, c1n, s_t, c.gpre, g1,
+                               d.h2_first_lstm ? 6 : 5 /* without h2 in the input the shift-gate block has no recurrent part */);
         }
         {   // S2
             GemmBuilder g;

@@ -95,8 +95,10 @@ __global__ void k_scatter_add_rows(const float* __restrict__ dx, const int* __re
 // ---------------------------------------------------------------------------------------------- forward saves
 // LSTM1 + gates, training flavour: also stores the post-activation gates (B, 6H) = [i f g o s_gate .]
 __global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ vproj,
+                              const float* __restrict__ xproj /* (M, 6H) embedding part of this step, projected for all steps at once */,
                               const float* __restrict__ c1_old, int M, int H, float* __restrict__ h1n, float* __restrict__ c1n,
-                              float* __restrict__ s_t, float* __restrict__ gpre, float* __restrict__ gates) {
+                              float* __restrict__ s_t, float* __restrict__ gpre, float* __restrict__ gates,
+                              int nblk /* column blocks (of 6) that the recurrent GEMM wrote */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
@@ -105,8 +107,9 @@ __global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long lo
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
-        q[g] = s + vproj[base + (long long)g * H];
+        if (g < nblk)
+            for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        q[g] = s + xproj[base + (long long)g * H] + vproj[base + (long long)g * H];
     }
     const float ig = sigmoidf_(q[0]), fg = sigmoidf_(q[1]), gg = tanhf(q[2]), og = sigmoidf_(q[3]), sg = sigmoidf_(q[4]);
     const float c = fg * c1_old[i] + ig * gg;
