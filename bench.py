@@ -115,7 +115,7 @@ def train_bench(args):
                                     att_size=c["A"], verb_2_vob_all={})
     m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     m = m.to(dev).train()
-    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4, fused=True)      # train.py:77 Adam(lr=5e-4); one fused launch per step instead of ~40 foreach kernels
     xe = args.workload == "xe"
     L = c["T"] if xe else c["L"]
     batches = []
@@ -176,10 +176,10 @@ def train_bench(args):
             "value": world * c["B"] * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("XE training step (forward + NLL losses + BPTT backward + Adam), batch 100/GPU, 20 slots x 36 regions x 2048-d, "
+            "config": {"workload": ("XE training step (forward + NLL losses + BPTT backward + torch.optim.Adam(fused=True)), batch 100/GPU, 20 slots x 36 regions x 2048-d, "
                                     "seq_len 20, vocab 10000 (BASELINE configs[3], fp32)") if xe else
                                    ("SCST step: greedy baseline (100 images) + sample_rl on 500 rows (5 samples/image) + replayed forward + BPTT "
-                                    "backward + Adam, 10 slots x 36 x 2048 (BASELINE configs[4], fp32)"),
+                                    "backward + Adam(fused=True), 10 slots x 36 x 2048 (BASELINE configs[4], fp32)"),
                        "batch_per_gpu": c["B"], "seq_len": c["T"], "parallelism": "dp%d, RCCL gradient all-reduce" % world},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
