@@ -252,6 +252,45 @@ def test_ragged_batch_sizes_and_max_beam():
         m.test(det, ctrl)                                              # CPU tensors: no fallback
 
 
+@pytest.mark.parametrize("beam", [2, 6, 8])
+def test_wide_vocabulary_selection_paths(beam):
+    """V >= 4096 takes the 512-thread vocabulary kernel: top-K from the wave-maxima threshold + candidate list
+    (beam = 8 = its number of waves is the boundary case), against the oracle's full sort."""
+    import vsr_oracle as vo
+    from vsrcap import synth
+    cfg = dict(V=4500, B=3, R0=6, R=5, D=64, L=3, T=5, E=32, H=48, A=16)
+    w = synth.make_weights(cfg["V"], cfg["D"], cfg["E"], cfg["H"], cfg["A"], seed=8)
+    m = helpers.build_model(cfg, w, DEV)
+    o = vo.Oracle(w, cfg["T"], 2, as_written=False)
+    det, ctrl = helpers.decode_inputs(cfg, 41)
+    with torch.no_grad():
+        (obw, obg), _, osc = o.beam_search(det, ctrl, [3, -1], beam, 2, return_scores=True)
+        eng = m._engine(torch.device(DEV))
+        B = eng.prepare(det.to(DEV), ctrl.to(DEV), beam, m._weights_version())
+        (bw, bg), _, sc = eng.beam(B, torch.device(DEV), beam, 2, 3, -1)
+    np.testing.assert_array_equal(bw.cpu().numpy(), obw.numpy())
+    np.testing.assert_array_equal(bg.cpu().numpy(), obg.numpy())
+    np.testing.assert_allclose(sc.cpu().numpy(), osc.numpy(), atol=1e-4, rtol=0)
+
+
+def test_constant_logit_rows_fall_back_to_full_row_selection():
+    """every vocabulary logit equal (zero output layer): more candidates tie with the threshold than the candidate list
+    holds, the kernel falls back to K full-row arg-max rounds; ties resolve to the lowest ids."""
+    from vsrcap import synth
+    cfg = dict(V=4500, B=2, R0=6, R=5, D=64, L=3, T=4, E=32, H=48, A=16)
+    w = synth.make_weights(cfg["V"], cfg["D"], cfg["E"], cfg["H"], cfg["A"], seed=8)
+    w["out_fc.weight"] = np.zeros_like(w["out_fc.weight"])
+    w["out_fc.bias"] = np.zeros_like(w["out_fc.bias"])
+    m = helpers.build_model(cfg, w, DEV)
+    det, ctrl = helpers.decode_inputs(cfg, 41)
+    with torch.no_grad():
+        (bw, bg), (lw, _) = m.beam_search((det.to(DEV), ctrl.to(DEV)), [cfg["V"] - 1, -1], 5, 5)   # an eos id that cannot be emitted
+        gw, _ = m.test(det.to(DEV), ctrl.to(DEV))
+    assert int(bw.max()) < 5 and int(bw.min()) >= 0                  # only the five lowest ids can ever be selected
+    assert (gw == 0).all()                                           # arg-max of a constant row: id 0
+    np.testing.assert_allclose(lw[:, 0].cpu().numpy(), -np.log(cfg["V"]), atol=1e-5)
+
+
 def test_eos_on_both_streams_freezes_hypotheses():
     """eos on BOTH streams exercises the freeze branch of beam_search (CaptioningModel.py:143-150)."""
     import vsr_oracle as vo
