@@ -343,12 +343,15 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     // scores: wave w takes rows w, w+4, ... of [regions ; sentinel]; four rows per pass so that their projection
     // loads are all in flight before the first tanh (one L2 round trip per pass instead of one per row)
     const float* mk_row = rmask + sl * R;
-    for (int r0 = wave; r0 < R + 1; r0 += 4 * NW) {
-        float sc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int a = lane * 4; a < A; a += 256) {
-            float4 p[4];
+    constexpr int QN = NT == 512 ? 5 : 4;        // rows per wave and pass: 8 waves x 5 cover the 37 score rows of R = 36 at once
+    for (int r0 = wave; r0 < R + 1; r0 += QN * NW) {
+        float sc[QN];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < QN; ++q) sc[q] = 0.f;
+        for (int a = lane * 4; a < A; a += 256) {
+            float4 p[QN];
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
                 const int r = r0 + NW * q;
                 const float* src = (r < R) ? P + (long long)ri_s[r] * A : sa_row;
                 // padding rows were never projected (att_va(0) = 0): their P entry is not defined, use the exact zero
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
             const float4 wa = *reinterpret_cast<const float4*>(w_a + a);
             const float4 ws = *reinterpret_cast<const float4*>(w_s + a);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < QN; ++q) {
                 const int r = r0 + NW * q;
                 const float4 w = (r < R) ? wa : ws;
                 sc[q] += w.x * tanhf(p[q].x + h.x);
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < QN; ++q) {
             const int r = r0 + NW * q;
             const float v = wave_sum(sc[q]);
             if (lane == 0 && r < R + 1) z_s[(r < R) ? r + 1 : 0] = v;
@@ -423,18 +426,19 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
         const float4 s = *reinterpret_cast<const float4*>(srow + d);
         float4 acc = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
         int r = 0;
-        for (; r + 8 <= R; r += 8) {
-            float al[8];
+        constexpr int CH = 12;                     // region rows in flight per thread
+        for (; r + CH <= R; r += CH) {
+            float al[CH];
             bool any = false;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { al[q] = z_s[r + 1 + q]; any |= al[q] != 0.f; }
+            for (int q = 0; q < CH; ++q) { al[q] = z_s[r + 1 + q]; any |= al[q] != 0.f; }
             if (!any) continue;
-            float4 x[8];
+            float4 x[CH];
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < CH; ++q)
                 x[q] = al[q] != 0.f ? *reinterpret_cast<const float4*>(regions + (long long)ri_s[r + q] * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < CH; ++q) {
                 acc.x += al[q] * x[q].x; acc.y += al[q] * x[q].y; acc.z += al[q] * x[q].z; acc.w += al[q] * x[q].w;
             }
         }
