@@ -133,8 +133,14 @@ def train_bench(args):
         for det, reg, _, _ in batches:
             rl_batches.append((det.repeat_interleave(NS, 0).contiguous(), reg.repeat_interleave(NS, 0).contiguous()))
 
-    def score(words):               # rewards are an INPUT of the RL step (CIDEr is out of scope): synthetic, on device
-        return (words.sum(1) % 97).float() / 97.0
+    # rewards: per-sample CIDEr-D on the device (vsrcap/reward.py; train.py:169-170) of the sampled / greedy
+    # captions against the batch's synthetic reference caption, document frequencies from a synthetic corpus of 2 000 captions
+    if not xe:
+        from vsrcap.reward import CiderD, clean_ids
+        corpus = [[clean_ids(cap, eos=EOS)] for cap in synth.make_captions(2000, c["T"], c["V"], seed=77)]
+        cider = CiderD(corpus, c["V"])
+        refs = [caps.unsqueeze(1).contiguous() for _, _, caps, _ in batches]               # (B, 1, T): one reference per sample
+        refs5 = [r.repeat_interleave(NS, 0).contiguous() for r in refs]
 
     def one_step(i):
         det, reg, caps, gts = batches[i & 1]
@@ -144,9 +150,9 @@ def train_bench(args):
             m.eval()
             base_words, _ = m.test(det, reg)
             m.train()
-        r_base = score(base_words).repeat_interleave(NS, 0)
+        r_base = cider.rewards(base_words, refs[i & 1], EOS).repeat_interleave(NS, 0)
         det5, reg5 = rl_batches[i & 1]
-        return step.scst_step(det5, reg5, lambda words: (score(words), r_base))
+        return step.scst_step(det5, reg5, lambda words: (cider.rewards(words, refs5[i & 1], EOS), r_base))
 
     def barrier():
         if world > 1:
@@ -172,14 +178,14 @@ def train_bench(args):
     if rank == 0:
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         line = {
-            "metric": "XE-step samples/sec" if xe else "SCST-step images/sec (5 samples/image + greedy baseline, rewards given)",
+            "metric": "XE-step samples/sec" if xe else "SCST-step images/sec (5 samples/image + greedy baseline, CIDEr-D rewards on device)",
             "value": world * c["B"] * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("XE training step (forward + NLL losses + BPTT backward + torch.optim.Adam(fused=True)), batch 100/GPU, 20 slots x 36 regions x 2048-d, "
                                     "seq_len 20, vocab 10000 (BASELINE configs[3], fp32)") if xe else
                                    ("SCST step: greedy baseline (100 images) + sample_rl on 500 rows (5 samples/image) + replayed forward + BPTT "
-                                    "backward + Adam(fused=True), 10 slots x 36 x 2048 (BASELINE configs[4], fp32)"),
+                                    "backward + Adam(fused=True), rewards = device CIDEr-D vs synthetic references, 10 slots x 36 x 2048 (BASELINE configs[4], fp32)"),
                        "batch_per_gpu": c["B"], "seq_len": c["T"], "parallelism": "dp%d, RCCL gradient all-reduce" % world},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,

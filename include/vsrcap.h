@@ -186,6 +186,19 @@ int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, const float*
 /* test hook: copy an internal buffer of the saved training pass ("dpre1", "dpre2", "dh2_voc", "gates1", ...) */
 int vsr_debug_copy(vsr_handle* h, const char* name, float* dst, size_t n_floats, void* stream);
 
+/* ---- SCST reward on the device ------------------------------------------------------
+ * Per-sample CIDEr-D on token ids: replaces the host section of the RL step, coco_scripts/train.py:154-172 (D2H of the
+ * sampled ids, TextField.decode, groupby de-duplication, PTBTokenizer, speaksee.evaluation.Cider.compute_score, H2D).
+ * speaksee==0.0.1 is absent: the algorithm is coco-caption's published CIDEr-D (oracle/cider_oracle.py, parity unpinned).
+ *   keys[k] / idf[k] / counts[k], k = 0..3: the corpus table of order k + 1 built once from the training references
+ *     (train.py:67): sorted keys = ids packed 16 bits each (first id lowest), idf = log(#samples) - log(max(1, df));
+ *     ref_len = log(#samples).  All on the device except `counts` (host).
+ *   cand (N, T) int64, refs (N, n_ref, Tr) int64: captions end at `eos` or `pad`; consecutive repeats collapse; ids with
+ *     drop[id] != 0 (punctuation, V bytes, may be NULL) are removed; rewards (N) fp32.  T, Tr <= 64, V <= 65535. */
+int vsr_cider_rewards(const uint64_t* const* keys, const double* const* idf, const int32_t* counts, double ref_len,
+                      const int64_t* cand, int32_t N, int32_t T, const int64_t* refs, int32_t n_ref, int32_t Tr,
+                      int64_t eos, int64_t pad, const uint8_t* drop, int32_t V, double sigma, float* rewards, void* stream);
+
 /* ---- measurement (bench.py roofline leg) ------------------------------------------------------------ */
 /* Between begin and end every fp32-MFMA GEMM launch is bracketed by a pair of pre-created HIP events on the
  * caller's stream.  end() synchronises the stream and returns the summed launch durations, the number of

@@ -65,6 +65,7 @@ SIGNATURES = {
     "vsr_train_forward": (I32, [P, P, P, I32, P, P, P, SZ, P]),
     "vsr_train_backward": (I32, [P, P, P, C.POINTER(VsrWeights), P]),
     "vsr_debug_copy": (I32, [P, C.c_char_p, P, SZ, P]),
+    "vsr_cider_rewards": (I32, [P, P, P, C.c_double, P, I32, I32, P, I32, I32, I64, I64, P, I32, C.c_double, P, P]),
     "vsr_profile_begin": (I32, [P]),
     "vsr_profile_begin_sampled": (I32, [P, I32]),
     "vsr_profile_seen": (I64, [P]),
