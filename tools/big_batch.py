@@ -1,0 +1,22 @@
+"""Robustness probe: one beam-5 call over 1 024 images, checked against a 128-image call on a slice of the same data (GPU box only)."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "vsr-guided-cic_amd"))
+import torch, numpy as np
+from vsrcap import synth
+from models import ControllableCaptioningModel
+c = dict(B=1024, R0=36, R=36, D=2048, L=10, T=20, V=10000, E=1000, H=1000, A=512)
+w = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=0)
+m = ControllableCaptioningModel(c["T"], c["V"], 2, det_feat_size=c["D"], input_encoding_size=c["E"], rnn_size=c["H"], att_size=c["A"], verb_2_vob_all={})
+m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}); m = m.cuda().eval()
+det = torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=5)).cuda()
+ctrl = torch.from_numpy(synth.make_ctrl(c["B"], c["L"], c["R"], c["D"], seed=5)).cuda()
+with torch.no_grad():
+    (w_all, g_all), _ = m.beam_search((det, ctrl), [3, -1], 5, 1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    (w_all, g_all), _ = m.beam_search((det, ctrl), [3, -1], 5, 1)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    (w_sub, g_sub), _ = m.beam_search((det[100:228].contiguous(), ctrl[100:228].contiguous()), [3, -1], 5, 1)
+same = (w_all[100:228] == w_sub).all().item() and (g_all[100:228] == g_sub).all().item()
+mism = int((w_all[100:228] != w_sub).any(1).sum())
+print("B=1024 beam-5: %.1f ms, %.0f tokens/s; rows 100..227 identical to a 128-image call: %s (%d captions differ)" % (dt * 1e3, c["B"] * c["T"] / dt, same, mism))
+print("peak memory GB", torch.cuda.max_memory_allocated() / 2**30)
