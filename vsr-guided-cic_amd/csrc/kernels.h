@@ -489,10 +489,28 @@ struct GateLogitArgs {
 // one wave per row
 __device__ __forceinline__ void gatelogit_row(const GateLogitArgs& g, int row, int lane) {
     float s = 0.f;
-    for (int a = lane; a < g.A; a += 64) {
-        float x = 0.f;
-        for (int k = 0; k < g.nsplit; ++k) x += g.ga[k * g.stride + (long long)row * g.A + a];
-        s += g.w_g[a] * tanhf(x + g.hA[(long long)row * g.A + a]);
+    // eight columns per lane and round, every slab of every column loaded before the first tanh (the row is one wave's
+    // latency chain: A / 64 dependent rounds otherwise)
+    for (int a0 = lane; a0 < g.A; a0 += 64 * 8) {
+        float x[8], h[8], wv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int a = a0 + 64 * q;
+            const bool in = a < g.A;
+            h[q] = in ? g.hA[(long long)row * g.A + a] : 0.f;
+            wv[q] = in ? g.w_g[a] : 0.f;
+            x[q] = 0.f;
+        }
+        for (int k = 0; k < g.nsplit; ++k) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int a = a0 + 64 * q;
+                if (a < g.A) x[q] += g.ga[k * g.stride + (long long)row * g.A + a];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (a0 + 64 * q < g.A) s += wv[q] * tanhf(x[q] + h[q]);
     }
     s = wave_sum(s);
     if (lane == 0) {
@@ -507,6 +525,37 @@ __device__ __forceinline__ void gatelogit_row(const GateLogitArgs& g, int row, i
         g.lg[(long long)row * g.lg_stride] = l0;
         g.lg[(long long)row * g.lg_stride + 1] = l1;
     }
+}
+
+// the same row by a whole workgroup (the vocabulary kernel's blocks do their row's gate logits on the side): one column
+// per thread, wave sums combined in wave order
+template <int NT>
+__device__ __forceinline__ void gatelogit_block(const GateLogitArgs& g, int row, float* red /* NT / 64 floats of LDS */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f;
+    for (int a = tid; a < g.A; a += NT) {
+        float x = 0.f;
+        for (int k = 0; k < g.nsplit; ++k) x += g.ga[k * g.stride + (long long)row * g.A + a];
+        s += g.w_g[a] * tanhf(x + g.hA[(long long)row * g.A + a]);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float a = 0.f;
+        for (int w = 0; w < NT / 64; ++w) a += red[w];
+        const float b = g.zsum[row];
+        const float mx = fmaxf(a, b);
+        const float lse = mx + logf(expf(a - mx) + expf(b - mx));
+        float l0 = a - lse, l1 = b - lse;
+        if (g.verbs) {
+            const float v = g.verbs[(long long)(row / g.rpi) * g.L + g.slot[row]];
+            if (v != -1.f) { l0 = -1e3f; l1 = 0.f; }
+        }
+        g.lg[(long long)row * g.lg_stride] = l0;
+        g.lg[(long long)row * g.lg_stride + 1] = l1;
+    }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void k_gatelogit(const GateLogitArgs g) {
@@ -556,14 +605,6 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
                                                const int* __restrict__ vt_ids, int n_verbs, int lds_row,
                                                const GateLogitArgs gate) {
     constexpr int NW = NT / 64;
-    // the first ceil(gate.M / NW) blocks compute the gate logits of this step (independent of the vocabulary rows: they
-    // ride in this launch, and go first so that their short latency-bound loops run under the vocabulary rows)
-    const int gate_blocks = (gate.M + NW - 1) / NW;
-    if ((int)blockIdx.x < gate_blocks) {
-        const int grow = (int)blockIdx.x * NW + (int)(threadIdx.x >> 6);
-        if (grow < gate.M) gatelogit_row(gate, grow, threadIdx.x & 63);
-        return;
-    }
     __shared__ float sv[NT * K];
     __shared__ int si[NT * K];
     __shared__ float red[2 * NW];
@@ -571,7 +612,9 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
     __shared__ int pick_s;
     extern __shared__ float lrow[];          // V floats when the launch passes dynamic LDS: the combined row is
     const bool use_lds = lds_row != 0;       // summed from the slabs ONCE and the later passes read it from LDS
-    const int row = (int)blockIdx.x - gate_blocks;
+    const int row = blockIdx.x;
+    // the gate logits of this row (independent of the vocabulary work; nothing reads them before the selection kernel)
+    if (gate.M > 0) gatelogit_block<NT>(gate, row, red);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = logits + (long long)row * V;
 

@@ -615,8 +615,8 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         if (g.launch(s, h)) return fail("S5 gemm launch failed");
         hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
                            w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n);
-        // the gate logits (z_g, log_softmax([z_g, zsum]), step :185-188) are nobody's input before the selection: they are
-        // computed by tail blocks of the vocabulary kernel's launch below instead of a launch of their own
+        // the gate logits (z_g, log_softmax([z_g, zsum]), step :185-188) are nobody's input before the selection: the
+        // vocabulary kernel's row blocks compute them on the side instead of a launch of their own
         gate_args = GateLogitArgs{c.ga_slabs, ns, stride_g, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A,
                                   io.lg_out, io.lg_stride};
     }
@@ -653,8 +653,8 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
         // K = beam exactly (fewer selection rounds than rounding up to a power of two); 512 threads per row from V = 4096 up
 #define VOCAB_LAUNCH(KK)                                                                                              \
-    if (V >= 4096) hipLaunchKernelGGL((k_vocab<KK, 512>), dim3(M + cdiv(M, 8)), dim3(512), vsm, s, VOCAB_ARGS);                  \
-    else hipLaunchKernelGGL((k_vocab<KK, 256>), dim3(M + cdiv(M, 4)), dim3(256), vsm, s, VOCAB_ARGS);                            \
+    if (V >= 4096) hipLaunchKernelGGL((k_vocab<KK, 512>), dim3(M), dim3(512), vsm, s, VOCAB_ARGS);                  \
+    else hipLaunchKernelGGL((k_vocab<KK, 256>), dim3(M), dim3(256), vsm, s, VOCAB_ARGS);                            \
     break;
         switch (io.K) {
             case 1: VOCAB_LAUNCH(1)
