@@ -67,29 +67,8 @@ __global__ __launch_bounds__(256) void k_rowmask(const float* __restrict__ X, lo
     if (lane == 0) mask[row] = (s != 0.f) ? 1.f : 0.f;
 }
 
-// list of the non-padding region rows (ascending) and their count: one 1024-thread block, chunked exclusive scan.
-// att_va(0) = 0 (no bias), so the hoisted region projection only has to run over these rows.
-__global__ __launch_bounds__(1024) void k_compact_rows(const float* __restrict__ mask, int rows, int* __restrict__ vlist, int* __restrict__ count) {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x;
-    const int per = (rows + 1023) / 1024;
-    const int r0 = tid * per, r1 = min(rows, r0 + per);
-    int n = 0;
-    for (int r = r0; r < r1; ++r) n += mask[r] != 0.f;
-    part[tid] = n;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {           // Hillis-Steele inclusive scan
-        const int v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int pos = part[tid] - n;
-    for (int r = r0; r < r1; ++r)
-        if (mask[r] != 0.f) vlist[pos++] = r;
-    if (tid == 1023) *count = part[1023];
-}
-
+// list of the non-padding region rows (ascending) and their count: att_va(0) = 0 (no bias), so the hoisted region
+// projection only has to run over these rows.  (k_compact_count / k_compact_scan / k_compact_write below.)
 // Index-list region format: slot entry (b, l, r) names row slot_idx[b,l,r] of image row_img[b]'s feature
 // bank (-1 = padding).  ridx = absolute bank row (or -1), rmask = the reference's row mask of the dense tensor the list
 // stands for (an all-zero bank row is masked exactly as its dense copy would be).  bad counts out-of-range indices.
@@ -146,6 +125,50 @@ __global__ __launch_bounds__(64) void k_reorder_slots(const int* __restrict__ sl
             const int rk = rank[(long long)n * L + j];
             verbs_out[(long long)n * L + j] = (rk >= 0 && rk < L) ? verbs_in[(long long)n * L + rk] : -1.f;
         }
+}
+
+// Three small launches (a single 1024-thread block walking its rows serially took 42-100 us): per-256-row counts, an exclusive scan of the (<= 4096 x 1024) block counts, ordered writes.
+__global__ __launch_bounds__(256) void k_compact_count(const float* __restrict__ mask, int rows, int* __restrict__ bcount) {
+    __shared__ int wsum[4];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const bool v = r < rows && mask[r] != 0.f;
+    const int n = __popcll(__ballot(v));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) bcount[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(1024) void k_compact_scan(int* __restrict__ bcount, int nblocks, int* __restrict__ total) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = tid * per, b1 = min(nblocks, b0 + per);
+    int n = 0;
+    for (int b = b0; b < b1; ++b) n += bcount[b];
+    part[tid] = n;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - n;                       // exclusive prefix of this thread's blocks
+    for (int b = b0; b < b1; ++b) { const int c = bcount[b]; bcount[b] = run; run += c; }
+    if (tid == 1023) *total = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_compact_write(const float* __restrict__ mask, int rows, const int* __restrict__ boffset,
+                                                       int* __restrict__ vlist) {
+    __shared__ int wsum[4];
+    const int r = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool v = r < rows && mask[r] != 0.f;
+    const unsigned long long bal = __ballot(v);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int base = boffset[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (v) vlist[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
 }
 
 // P[vlist[m]] = sum of the slabs' row m   (scatter of the compact projection back to the dense row index)

@@ -55,6 +55,7 @@ struct Ctx {
     float* dmask = nullptr;      // row masks of the detection rows (pooled descriptor)
     float *vbar, *vproj, *vproj2, *P, *rmask;
     int *vlist, *nvalid_dev;     // non-padding region rows (ascending) and their number
+    int* bcount;                 // per-256-row counts / offsets of the compaction
     int nvalid = 0;
     float* st[2][4];   // h1, c1, h2, c2 double-buffered
     int *slot[2], *word[2], *gate[2], *parent;
@@ -136,6 +137,7 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     }
     c.dmask = b.take<float>((size_t)(c.Rb > 0 ? c.n_img : B) * c.R0);
     c.vlist = b.take<int>(prows);
+    c.bcount = b.take<int>((prows + 255) / 256 + 1);
     c.nvalid_dev = b.take<int>(4);
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 4; ++j) c.st[i][j] = b.take<float>(M * H);
@@ -412,7 +414,12 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
         hipLaunchKernelGGL(k_index_rows, dim3(cdiv(rows, 256)), dim3(256), 0, s, slot_idx, row_img, c.bmask, B, L * R, Rb, n_img,
                            c.ridx_buf, c.rmask, c.nvalid_dev + 1);
     }
-    hipLaunchKernelGGL(k_compact_rows, dim3(1), dim3(1024), 0, s, c.bmask, (int)prows, c.vlist, c.nvalid_dev);
+    {
+        const int nb = (int)cdiv(prows, 256);
+        hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(256), 0, s, c.bmask, (int)prows, c.bcount);
+        hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, s, c.bcount, nb, c.nvalid_dev);
+        hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, s, c.bmask, (int)prows, c.bcount, c.vlist);
+    }
     LAUNCHCHK();
     if (!h->host_back) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->host_back), 2 * sizeof(int), hipHostMallocDefault));
     int* back = h->host_back;                                            // pinned: the copy does not block this thread
