@@ -252,13 +252,14 @@ def test_ragged_batch_sizes_and_max_beam():
         m.test(det, ctrl)                                              # CPU tensors: no fallback
 
 
-@pytest.mark.parametrize("beam", [2, 6, 8])
-def test_wide_vocabulary_selection_paths(beam):
+@pytest.mark.parametrize("beam,V,D", [(2, 4500, 64), (6, 4500, 64), (8, 4500, 64), (5, 4501, 2052)])
+def test_wide_vocabulary_selection_paths(beam, V, D):
     """V >= 4096 takes the 512-thread vocabulary kernel: top-K from the wave-maxima threshold + candidate list
     (beam = 8 = its number of waves is the boundary case), against the oracle's full sort."""
     import vsr_oracle as vo
     from vsrcap import synth
-    cfg = dict(V=4500, B=3, R0=6, R=5, D=64, L=3, T=5, E=32, H=48, A=16)
+    # V = 4501: not a multiple of 4 (scalar row loads); D = 2052: the 512-thread attention kernel with a ragged last pass
+    cfg = dict(V=V, B=3, R0=6, R=5, D=D, L=3, T=5, E=32, H=48, A=16)
     w = synth.make_weights(cfg["V"], cfg["D"], cfg["E"], cfg["H"], cfg["A"], seed=8)
     m = helpers.build_model(cfg, w, DEV)
     o = vo.Oracle(w, cfg["T"], 2, as_written=False)
