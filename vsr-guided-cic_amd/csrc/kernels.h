@@ -11,6 +11,19 @@ namespace vsr {
 
 constexpr int KMAX = 8;  // VSR_MAX_BEAM
 
+// sum of up to 8 slabs at one offset, in slab order, with every load issued before the first add (the slab count is a
+// run-time number: a plain loop is a chain of dependent L2 round trips)
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, int nslab, long long stride) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < nslab ? p[k * stride] : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (k < nslab) s += v[k];
+    return s;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -248,9 +261,7 @@ __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long str
     float q[6];
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
-        float s = 0.f;
-        if (g < nblk)
-            for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        float s = g < nblk ? slab_sum(pre + base + (long long)g * H, nsplit, stride) : 0.f;
         if (xp) s += xp[(long long)g * H];
         q[g] = s + vp[(long long)g * H];
     }
@@ -336,8 +347,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     if (fused) {
         const int H = g2.H;
         for (int c = tid; c < H + A; c += NT) {
-            float s = 0.f;
-            for (int q = 0; q < g2.nsplit; ++q) s += g2.c2a[q * g2.stride_a + (long long)row * (H + A) + c];
+            const float s = slab_sum(g2.c2a + (long long)row * (H + A) + c, g2.nsplit, g2.stride_a);
             if (c < H) {
                 const long long o = (long long)row * H + c;
                 g2.g_t[o] = sigmoidf_(g2.gpre[o] + s) * tanhf(g2.c1n[o]);
@@ -347,8 +357,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
             }
         }
         for (int cc = tid; cc < D + A; cc += NT) {
-            float s = 0.f;
-            for (int q = 0; q < g2.nsplit; ++q) s += g2.c2b[q * g2.stride_b + (long long)row * (D + A) + cc];
+            const float s = slab_sum(g2.c2b + (long long)row * (D + A) + cc, g2.nsplit, g2.stride_b);
             if (cc < D) sent_s[cc] = s + g2.b_sfc[cc];
             else sa_s[cc - D] = s;
         }
@@ -488,8 +497,7 @@ __global__ void k_lstm2(const float* __restrict__ pre, int nsplit, long long str
     float q[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        float s = slab_sum(pre + base + (long long)g * H, nsplit, stride);
         s += b_ih[g * H + j] + b_hh[g * H + j];
         if (vproj2) s += vproj2[(long long)(row / rpi) * 4 * H + g * H + j];
         q[g] = s;
@@ -557,8 +565,7 @@ __device__ __forceinline__ void gatelogit_block(const GateLogitArgs& g, int row,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float s = 0.f;
     for (int a = tid; a < g.A; a += NT) {
-        float x = 0.f;
-        for (int k = 0; k < g.nsplit; ++k) x += g.ga[k * g.stride + (long long)row * g.A + a];
+        const float x = slab_sum(g.ga + (long long)row * g.A + a, g.nsplit, g.stride);
         s += g.w_g[a] * tanhf(x + g.hA[(long long)row * g.A + a]);
     }
     s = wave_sum(s);
