@@ -13,11 +13,11 @@ constexpr int KMAX = 8;  // VSR_MAX_BEAM
 
 // sum of up to 8 slabs at one offset, in slab order, with every load issued before the first add (the slab count is a
 // run-time number: a plain loop is a chain of dependent L2 round trips)
-__device__ __forceinline__ float slab_sum(const float* __restrict__ p, int nslab, long long stride) {
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, int nslab, long long stride, float init = 0.f) {
     float v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = k < nslab ? p[k * stride] : 0.f;
-    float s = 0.f;
+    float s = init;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (k < nslab) s += v[k];
@@ -190,8 +190,7 @@ __global__ void k_slab_reduce_scatter(const float* __restrict__ slabs, int nslab
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)rows * A) return;
     const int m = (int)(i / A), a = (int)(i % A);
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
+    float s = slab_sum(slabs + i, nslab, stride);
     P[(long long)vlist[m] * A + a] = s;
 }
 
@@ -204,8 +203,7 @@ __global__ void k_vproj_finish(const float* __restrict__ slabs, int nsplit, long
     const int N = 6 * H;
     if (i >= (long long)B * N) return;
     const int n = (int)(i % N);
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slabs[k * stride + i];
+    float s = slab_sum(slabs + i, nsplit, stride);
     float bias;
     if (n < 4 * H) bias = b_ih[n] + b_hh[n];
     else if (n < 5 * H) bias = b_is[n - 4 * H] + b_hs[n - 4 * H];
@@ -216,8 +214,7 @@ __global__ void k_vproj_finish(const float* __restrict__ slabs, int nsplit, long
 __global__ void k_slab_reduce(const float* __restrict__ slabs, int nsplit, long long stride, long long n, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slabs[k * stride + i];
+    float s = slab_sum(slabs + i, nsplit, stride);
     out[i] = s;
 }
 
@@ -286,8 +283,7 @@ __global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__
     if (i >= (long long)M * W) return;
     const int row = (int)(i / W), c = (int)(i % W);
     if (c < H + A) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += c2a[k * stride_a + (long long)row * (H + A) + c];
+        float s = slab_sum(c2a + (long long)row * (H + A) + c, nsplit, stride_a);
         if (c < H) {
             const long long o = (long long)row * H + c;
             const float gg = sigmoidf_(gpre[o] + s);
@@ -298,8 +294,7 @@ __global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__
         }
     } else {
         const int cc = c - (H + A);
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += c2b[k * stride_b + (long long)row * (D + A) + cc];
+        float s = slab_sum(c2b + (long long)row * (D + A) + cc, nsplit, stride_b);
         if (cc < D) sent[(long long)row * D + cc] = s + b_sfc[cc];
         else sa[(long long)row * A + (cc - D)] = s;
     }

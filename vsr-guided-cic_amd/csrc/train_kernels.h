@@ -43,8 +43,7 @@ __global__ void k_slab_reduce_2d(const float* __restrict__ slabs, int nslab, lon
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)rows * w) return;
     const int r = (int)(i / w), c = (int)(i % w);
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
+    float s = slab_sum(slabs + i, nslab, stride);
     dst[(long long)r * ldd + c] = s;
 }
 
@@ -106,9 +105,7 @@ __global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long lo
     float q[6];
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
-        float s = 0.f;
-        if (g < nblk)
-            for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        const float s = g < nblk ? slab_sum(pre + base + (long long)g * H, nsplit, stride) : 0.f;
         q[g] = s + xproj[base + (long long)g * H] + vproj[base + (long long)g * H];
     }
     const float ig = sigmoidf_(q[0]), fg = sigmoidf_(q[1]), gg = tanhf(q[2]), og = sigmoidf_(q[3]), sg = sigmoidf_(q[4]);
@@ -131,8 +128,7 @@ __global__ void k_lstm2_train(const float* __restrict__ pre, int nsplit, long lo
     float q[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += pre[k * stride + base + (long long)g * H];
+        float s = slab_sum(pre + base + (long long)g * H, nsplit, stride);
         s += b_ih[g * H + j] + b_hh[g * H + j];
         if (vproj2) s += vproj2[base + (long long)g * H];
         q[g] = s;
@@ -401,9 +397,7 @@ __global__ void k_slab_cols_multi(const SlabJobs jobs) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)jobs.rows * q.w) return;
     const int r = (int)(i / q.w), c = (int)(i % q.w);
-    float s = q.add ? q.add[i] : 0.f;
-    for (int k = 0; k < q.nslab; ++k) s += q.slabs[k * q.stride + (long long)r * q.ld + q.c0 + c];
-    q.out[i] = s;
+    q.out[i] = slab_sum(q.slabs + (long long)r * q.ld + q.c0 + c, q.nslab, q.stride, q.add ? q.add[i] : 0.f);
 }
 
 __global__ void k_slab_cols(const float* __restrict__ slabs, int nslab, long long stride, int ld, int c0, int w, int rows,
@@ -411,9 +405,7 @@ __global__ void k_slab_cols(const float* __restrict__ slabs, int nslab, long lon
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)rows * w) return;
     const int r = (int)(i / w), c = (int)(i % w);
-    float s = add ? add[i] : 0.f;
-    for (int k = 0; k < nslab; ++k) s += slabs[k * stride + (long long)r * ld + c0 + c];
-    out[i] = s;
+    out[i] = slab_sum(slabs + (long long)r * ld + c0 + c, nslab, stride, add ? add[i] : 0.f);
 }
 
 }  // namespace vsr
