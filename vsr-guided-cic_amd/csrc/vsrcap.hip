@@ -88,6 +88,7 @@ struct vsr_handle {
     const int* vt_ids = nullptr;
     int n_verbs = 0;
     int gemm_slots = 1024;       // resident 64x64 GEMM workgroups to fill: 256 CUs x 4 (36.9 KB LDS each)
+    int gemm_slots_small = 768;  // 64x64 tiles (M <= 192): 3 per CU measured best (greedy 473 k vs 461 k tokens/s at 4 per CU)
     int gemm_min_iters = 8;
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
     int gemm_dma = 0;            // VSR_GEMM_DMA=1: LDS-DMA 3-stage variant for the 128x64 tile (measured equal: DESIGN.md)
@@ -203,7 +204,7 @@ struct GemmBuilder {
         // 128x128 for M >= 1024 (weight-gradient GEMMs: one tile per workgroup, 130 TF/s at long K);
         // 128x64 is the default for tall problems: as fast as 128x128 in the GEMM itself (91.8 vs 93.7 TF/s) but its
         // tiles are cut into ~3 stream-K pieces instead of ~5, so every consumer kernel reads 40 % fewer slab bytes.
-        return gemm_plan(a, big ? h->gemm_slots / 2 : h->gemm_slots, h->gemm_min_iters, big ? 128 : 64, big == 2 ? 128 : 64);
+        return gemm_plan(a, big ? h->gemm_slots / 2 : h->gemm_slots_small, h->gemm_min_iters, big ? 128 : 64, big == 2 ? 128 : 64);
     }
     int launch(hipStream_t s, vsr_handle* h);
 };
@@ -246,9 +247,12 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     h->tc = new_train_ctx();
     hipDeviceProp_t prop;
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
         h->gemm_slots = prop.multiProcessorCount * 4;
+        h->gemm_slots_small = prop.multiProcessorCount * 3;
+    }
     if (const char* e = getenv("VSR_GEMM_SLOTS")) h->gemm_slots = std::max(1, atoi(e));
+    if (const char* e = getenv("VSR_GEMM_SLOTS_SMALL")) h->gemm_slots_small = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e);
     if (const char* e = getenv("VSR_GEMM_DMA")) h->gemm_dma = atoi(e);
     if (const char* e = getenv("VSR_GEMM_MIN_ITERS")) h->gemm_min_iters = std::max(1, atoi(e));
