@@ -3,7 +3,6 @@ header declares; the ctypes binding covers every symbol (no compute without a GP
 import os
 import re
 
-import pytest
 
 from conftest import ROOT
 

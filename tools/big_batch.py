@@ -1,7 +1,7 @@
 """Robustness probe: one beam-5 call over 1 024 images, checked against a 128-image call on a slice of the same data (GPU box only)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "vsr-guided-cic_amd"))
-import torch, numpy as np
+import torch
 from vsrcap import synth
 from models import ControllableCaptioningModel
 c = dict(B=1024, R0=36, R=36, D=2048, L=10, T=20, V=10000, E=1000, H=1000, A=512)
