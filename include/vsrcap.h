@@ -156,9 +156,16 @@ int vsr_beam(vsr_handle* h, int32_t beam, int32_t out_size, int64_t eos_word, in
              int32_t gt, int64_t* words, int64_t* gates, float* lp_words, float* lp_gates, float* scores, void* stream);
 
 /* ---- teacher forcing (CaptioningModel.forward :22-36) --------------------------------------------- */
-/* captions (B,T) int64; prepare() must have been called with regions = seqs[1] (B,T,R,D), beam = 1.
- * logp_words (B,T,V), logp_gates (B,T,2). */
+/* captions (B,T) int64; prepare() must have been called with regions = seqs[1] (B,L,R,D), L >= T (forward() only
+ * needs ctrl_seq.size(1) >= captions.size(1): step t reads slot t), beam = 1.  logp_words (B,T,V), logp_gates (B,T,2). */
 int vsr_xe_forward(vsr_handle* h, const int64_t* captions, int32_t T, float* logp_words, float* logp_gates, void* stream);
+
+/* ---- input contract check --------------------------------------------------------------------------------
+ * Word ids outside [0, V) (nn.Embedding raises on them, controllable_captioning.py:144), slot traces outside [0, L),
+ * replayed gates outside {0, 1} and gt-verb ids outside [0, V) (step_v :280) are CLAMPED on the device - never an
+ * out-of-bounds access - and counted.  *count = ids clamped by the calls since the last vsr_prepare*() or vsr_bad_ids();
+ * the call synchronises the stream and resets the counter. */
+int vsr_bad_ids(vsr_handle* h, int32_t* count, void* stream);
 
 /* ---- single timestep (ControllableCaptioningModel.step / step_v :117-297), feedback mode ---------- */
 /* state in/out: h1,c1,h2,c2 (M,H) fp32 and slot (M) int64, M = B * rows_per_image (rows of one image
@@ -182,6 +189,11 @@ int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const int64_t* slot
                       float* logp_gates, void* train_workspace, size_t train_workspace_bytes, void* stream);
 int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, const float* grad_logp_gates, const vsr_weights* grads,
                        void* stream);
+/* The handle holds ONE saved forward at a time (the reference runs under eager autograd and has no such limit).
+ * vsr_train_generation() identifies it (0 = none, changes with every vsr_train_forward and every vsr_prepare*):
+ * a caller that may have several forwards alive (loss = l1 + l2, XE forward + sample_rl in one step, a second
+ * backward) records the value after its forward and refuses to call vsr_train_backward when it has changed. */
+int64_t vsr_train_generation(const vsr_handle* h);
 
 /* test hook: copy an internal buffer of the saved training pass ("dpre1", "dpre2", "dh2_voc", "gates1", ...) */
 int vsr_debug_copy(vsr_handle* h, const char* name, float* dst, size_t n_floats, void* stream);

@@ -228,9 +228,18 @@ __global__ void k_fill_i32(int* p, int v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
-__global__ void k_i64_to_i32(const int64_t* src, long long src_stride, int* dst, int n) {
+// int64 ids of the caller -> int32, range-checked: an id outside [0, hi) is counted in *bad and clamped, so that a
+// padding id of -1 or an id >= V never indexes the embedding / projection tables out of bounds (nn.Embedding raises
+// there; here the count is reported by vsr_bad_ids()).
+__global__ void k_i64_to_i32(const int64_t* src, long long src_stride, int* dst, int n, int hi, int* __restrict__ bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = (int)src[(long long)i * src_stride];
+    if (i >= n) return;
+    long long v = src[(long long)i * src_stride];
+    if (v < 0 || v >= hi) {
+        atomicAdd(bad, 1);
+        v = v < 0 ? 0 : hi - 1;
+    }
+    dst[i] = (int)v;
 }
 __global__ void k_i32_to_i64(const int* src, int64_t* dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
                                                const float* __restrict__ verbs, const int* __restrict__ slot, int rpi,
                                                int L, int gt, const int* __restrict__ vt_ptr,
                                                const int* __restrict__ vt_ids, int n_verbs, int lds_row,
-                                               const GateLogitArgs gate) {
+                                               const GateLogitArgs gate, int* __restrict__ bad) {
     constexpr int NW = NT / 64;
     __shared__ float sv[NT * K];
     __shared__ int si[NT * K];
@@ -652,8 +661,10 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
     if (verb != -1) {
         if (tid == 0) {
             int pick = 0;
-            if (gt) pick = verb;
-            else if (verb >= 0 && verb < n_verbs && vt_ptr[verb + 1] > vt_ptr[verb]) {
+            if (gt) {
+                pick = verb;
+                if (verb < 0 || verb >= V) { atomicAdd(bad, 1); pick = 0; }     // the reference's out[i, verb] = 0 would raise
+            } else if (verb >= 0 && verb < n_verbs && vt_ptr[verb + 1] > vt_ptr[verb]) {
                 float best = -1e6f;
                 pick = -1;
                 // the reference compares log-probs; logits differ by the row constant lse, so compare

@@ -14,6 +14,7 @@
 
 struct TrainCtx {
     bool valid = false;
+    long long generation = 0;          // bumped by every vsr_train_forward: identifies the saved forward a backward belongs to
     int B = 0, T = 0, TB = 0, TBp = 0, Bp = 0, RLp = 0;
     const float* logp_w = nullptr;     // caller's (B,T,V) output of the forward, needed by the backward
     const float* logp_g = nullptr;     // (B,T,2)
@@ -128,7 +129,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     Ctx& c = h->c;
     if (c.beam != 1 && c.Mmax != c.B) return fail("vsr_train_forward: prepare() must be called with beam = 1");
     if (c.ridx) return fail("vsr_train_forward: index-list regions (vsr_prepare_indexed) are a decode-side format; train on dense region tensors (vsr_prepare)");
-    if (!slots && T != c.L) return fail("vsr_train_forward: without a slot trace the regions must have one slot per step (T %d, L %d)", T, c.L);
+    if (!slots && (T < 1 || T > c.L)) return fail("vsr_train_forward: without a slot trace step t reads slot t: need 1 <= T <= L (T %d, L %d)", T, c.L);
     hipStream_t s = (hipStream_t)stream;
     const vsr_dims& d = h->d;
     const vsr_weights& w = h->w;
@@ -145,7 +146,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     HIPCHK(hipMemsetAsync(t.c1s, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.h2s, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.c2s, 0, BH * sizeof(float), s));
-    hipLaunchKernelGGL(k_train_indices, dim3(cdiv(TB, 256)), dim3(256), 0, s, word_in, slots, T, B, t.word32, t.slot32, t.rows_bt);
+    hipLaunchKernelGGL(k_train_indices, dim3(cdiv(TB, 256)), dim3(256), 0, s, word_in, slots, T, B, V, c.L, t.word32, t.slot32, t.rows_bt, c.nvalid_dev + 2);
     hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((long long)TB * E, 256)), dim3(256), 0, s, w.embed_weight, t.word32, TB, E, t.x_all);
     LAUNCHCHK();
     {   // the x part of every step's LSTM1 / gate pre-activations does not depend on the recurrence: one GEMM with M = T B
@@ -262,7 +263,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
         const GateLogitArgs no_gate{nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0, 0, 0, nullptr, 0};
 #define TRAIN_VOCAB_ARGS t.scratch, ns, stride, w.out_fc_bias, TB, V, (int)VM_FULL, c.top_v, c.top_i, logp_words, (long long)V, (const int*)nullptr, \
-                         (uint64_t)0, (uint32_t)0, (const float*)nullptr, (const int*)nullptr, 1, c.L, 0, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row, no_gate
+                         (uint64_t)0, (uint32_t)0, (const float*)nullptr, (const int*)nullptr, 1, c.L, 0, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row, no_gate, c.nvalid_dev + 2
         if (V >= 4096) hipLaunchKernelGGL((k_vocab<1, 512>), dim3(TB), dim3(512), vsm, s, TRAIN_VOCAB_ARGS);
         else hipLaunchKernelGGL((k_vocab<1, 256>), dim3(TB), dim3(256), vsm, s, TRAIN_VOCAB_ARGS);
 #undef TRAIN_VOCAB_ARGS
@@ -271,8 +272,13 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     t.logp_w = logp_words;
     t.logp_g = logp_gates;
     t.valid = true;
+    ++t.generation;
     return 0;
 }
+
+// Identity of the saved forward pass (0 = none).  The training workspace holds ONE forward at a time: a caller that keeps
+// several autograd nodes alive compares the value it got after its forward with the current one before differentiating.
+extern "C" int64_t vsr_train_generation(const vsr_handle* h) { return (h && h->tc && h->tc->valid) ? (int64_t)h->tc->generation : 0; }
 
 // dlogits in (t, b) row order from the (B, T, V) tensors
 __global__ __launch_bounds__(256) void k_dlogits_tb(const float* __restrict__ logp, const float* __restrict__ dlogp, int B, int T, int V,

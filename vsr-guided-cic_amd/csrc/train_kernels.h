@@ -378,13 +378,17 @@ __global__ void k_add3(const float* __restrict__ a, const float* __restrict__ b,
 // strided variant for slab sums: out[r][c] = sum_k slabs[k][r][c0 + c] (+ add[r][c])
 // (B, T) int64 captions / slot traces -> (T, B) int32 step-major copies, plus the (b, t)-ordered row list of the saved
 // states (row (t + 1) * B + b) that the batched vocabulary projection gathers through.  slots == null: slot = step.
-__global__ void k_train_indices(const int64_t* __restrict__ word_in, const int64_t* __restrict__ slots, int T, int B,
-                                int* __restrict__ word32, int* __restrict__ slot32, int* __restrict__ rows_bt) {
+__global__ void k_train_indices(const int64_t* __restrict__ word_in, const int64_t* __restrict__ slots, int T, int B, int V, int L,
+                                int* __restrict__ word32, int* __restrict__ slot32, int* __restrict__ rows_bt, int* __restrict__ bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T * B) return;
     const int tt = i / B, b = i - tt * B;
-    word32[i] = (int)word_in[(long long)b * T + tt];
-    slot32[i] = slots ? (int)slots[(long long)b * T + tt] : tt;
+    long long w = word_in[(long long)b * T + tt];
+    long long k = slots ? slots[(long long)b * T + tt] : tt;
+    if (w < 0 || w >= V) { atomicAdd(bad, 1); w = w < 0 ? 0 : V - 1; }      // counted, clamped: never an out-of-bounds gather
+    if (k < 0 || k >= L) { atomicAdd(bad, 1); k = k < 0 ? 0 : L - 1; }
+    word32[i] = (int)w;
+    slot32[i] = (int)k;
     rows_bt[b * T + tt] = (tt + 1) * B + b;
 }
 

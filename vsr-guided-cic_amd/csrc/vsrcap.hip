@@ -174,7 +174,7 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     // split-K slab scratch: the widest stage, 8 slabs
     size_t widest = std::max({6 * H, (H + A) + (D + A), 4 * H + A, V});
     size_t stage = std::max(M * widest, B * 6 * H);
-    c.scratch_floats = std::max(stage * 8, rows * A * 8);       // att_va slabs of prepare()
+    c.scratch_floats = std::max(stage * 8, std::max(rows, prows) * A * 8);   // att_va slabs of prepare(): over the bank rows when indexed
     c.scratch = b.take<float>(c.scratch_floats);
     c.pre1 = b.take<float>(M * 6 * H * 8);
     return (b.off + 255) & ~size_t(255);
@@ -413,8 +413,8 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     const long long rows = (long long)B * L * R;                         // slot entries
     const long long prows = indexed ? (long long)n_img * Rb : rows;      // rows att_va runs over
     hipLaunchKernelGGL(k_rowmask, dim3(cdiv(prows, 4)), dim3(256), 0, s, regions, prows, D, c.bmask);
+    HIPCHK(hipMemsetAsync(c.nvalid_dev, 0, 4 * sizeof(int), s));      // [0] row count, [1] bad slot indices, [2] bad word / slot / verb ids
     if (indexed) {
-        HIPCHK(hipMemsetAsync(c.nvalid_dev, 0, 4 * sizeof(int), s));
         hipLaunchKernelGGL(k_index_rows, dim3(cdiv(rows, 256)), dim3(256), 0, s, slot_idx, row_img, c.bmask, B, L * R, Rb, n_img,
                            c.ridx_buf, c.rmask, c.nvalid_dev + 1);
     }
@@ -478,6 +478,8 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
         GemmBuilder::seg(p0, regions, D, c.vlist, w.att_va_weight, D, D);
         const int ns = g.finish(h);
         const long long stride = (long long)c.nvalid * A;
+        if ((size_t)stride * ns > c.scratch_floats)
+            return fail("%s: att_va slabs (%lld x %d floats) exceed the workspace scratch (%zu)", who, stride, ns, c.scratch_floats);
         g.a.p[0].slab_stride = stride;
         if (g.launch(s, h)) return fail("att_va gemm launch failed");
         hipLaunchKernelGGL(k_slab_reduce_scatter, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.nvalid, A, c.vlist, c.P);
@@ -659,7 +661,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         c.pre1_ns = ns; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
         if (g.launch(s, h)) return fail("S6 gemm launch failed");
 #define VOCAB_ARGS c.scratch, ns, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
-                   io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row, gate_args
+                   io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row, gate_args, c.nvalid_dev + 2
         const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;          // combined logits row staged in LDS (<= 96 KB)
         const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
         // K = beam exactly (fewer selection rounds than rounding up to a power of two); 512 threads per row from V = 4096 up
@@ -701,6 +703,21 @@ static int zero_state(vsr_handle* h, int M, hipStream_t s) {
     return 0;
 }
 
+// Number of out-of-range ids (words outside [0, V), slots outside [0, L), gates outside {0, 1}, gt verbs outside [0, V)) the
+// calls since the last vsr_prepare*() / vsr_bad_ids() were handed.  Such ids are clamped on the device (no out-of-bounds
+// access); the reference would raise (nn.Embedding / tensor indexing).  Synchronises the stream; resets the count.
+extern "C" int vsr_bad_ids(vsr_handle* h, int32_t* count, void* stream) {
+    if (!h || !count) return fail("vsr_bad_ids: null argument");
+    if (!h->prepared) { *count = 0; return 0; }
+    hipStream_t s = (hipStream_t)stream;
+    int v = 0;
+    HIPCHK(hipMemcpyAsync(&v, h->c.nvalid_dev + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemsetAsync(h->c.nvalid_dev + 2, 0, sizeof(int), s));
+    *count = v;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- greedy / sampling
 static int decode_simple(vsr_handle* h, int vmode, uint64_t seed, const int64_t* forced_w, const int64_t* forced_g,
                          const float* verbs, int gt, int64_t* words, int64_t* gates, float* lp_w, float* lp_g, hipStream_t s) {
@@ -710,8 +727,8 @@ static int decode_simple(vsr_handle* h, int vmode, uint64_t seed, const int64_t*
     if (zero_state(h, B, s)) return 1;
     if (vmode == VM_FORCED) {
         for (int t = 0; t < T; ++t) {
-            hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, forced_w + t, (long long)T, c.forced_w32 + (size_t)t * B, B);
-            hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, forced_g + t, (long long)T, c.forced_g32 + (size_t)t * B, B);
+            hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, forced_w + t, (long long)T, c.forced_w32 + (size_t)t * B, B, h->d.vocab_size, c.nvalid_dev + 2);
+            hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, forced_g + t, (long long)T, c.forced_g32 + (size_t)t * B, B, 2, c.nvalid_dev + 2);
         }
     }
     for (int t = 0; t < T; ++t) {
@@ -799,13 +816,13 @@ extern "C" int vsr_xe_forward(vsr_handle* h, const int64_t* captions, int32_t T,
     if (check_ready(h, "vsr_xe_forward")) return 1;
     Ctx& c = h->c;
     if (!captions || !logp_words || !logp_gates) return fail("vsr_xe_forward: null tensor");
-    if (T != c.L) return fail("vsr_xe_forward: captions have %d steps but prepare() saw %d region slots", T, c.L);
+    if (T < 1 || T > c.L) return fail("vsr_xe_forward: captions have %d steps but prepare() saw %d region slots (need 1 <= T <= L: step t reads slot t)", T, c.L);
     if (T > h->d.seq_len) return fail("vsr_xe_forward: T %d exceeds seq_len %d (workspace is sized by seq_len)", T, h->d.seq_len);
     hipStream_t s = (hipStream_t)stream;
     const int B = c.B, V = h->d.vocab_size;
     if (zero_state(h, B, s)) return 1;
     for (int t = 0; t < T; ++t)
-        hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, captions + t, (long long)T, c.cap32 + (size_t)t * B, B);
+        hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, captions + t, (long long)T, c.cap32 + (size_t)t * B, B, V, c.nvalid_dev + 2);
     for (int t = 0; t < T; ++t) {
         StepIO io{};
         io.t = t; io.M = B; io.rpi = 1; io.cur = t & 1;
@@ -847,7 +864,7 @@ extern "C" int vsr_step(vsr_handle* h, int32_t t, int32_t rows_per_image, const 
     for (int j = 0; j < 4; ++j) HIPCHK(hipMemcpyAsync(c.st[0][j], in[j], n, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_step_slots, dim3(cdiv(M, 256)), dim3(256), 0, s, t, slot, prev_gates, c.L, M, c.slot[0], slot_out);
     if (t == 0) hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, c.word[0], h->d.bos_idx, M);
-    else hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, prev_words, 1LL, c.word[0], M);
+    else hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, prev_words, 1LL, c.word[0], M, V, c.nvalid_dev + 2);
     StepIO io{};
     io.t = 1;  // state segments are always live here (the caller may pass a non-zero state at t == 0)
     io.M = M; io.rpi = rows_per_image; io.cur = 0;

@@ -65,6 +65,14 @@ class ControllableCaptioningModel(CaptioningModel):
         self.init_weights()
         self._eng = None
         self._verb_dev = None
+        # prepare() caches the hoisted per-image tensors keyed on (data_ptr, tensor._version, shapes, weights version);
+        # set force_prepare = True when inputs / weights are rewritten in ways that do not bump _version
+        # (t.data.copy_, DLPack / custom-kernel writes, p.data edits), or call invalidate_cache() after such a write
+        self.force_prepare = False
+
+    def invalidate_cache(self):
+        if self._eng is not None:
+            self._eng.invalidate()
 
     def init_weights(self):
         for name, p in self.named_parameters():
@@ -84,12 +92,17 @@ class ControllableCaptioningModel(CaptioningModel):
         if device.type != 'cuda':
             raise RuntimeError("ControllableCaptioningModel (MI355X build) computes only on the GPU: move the model and "
                                "its inputs to 'cuda'. There is no CPU fallback.")
-        if self._eng is None:
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if self._eng is None or self._eng.device != device:
+            # one handle per device; its launches run under torch.cuda.device(device) whatever the caller's current device is
             self._eng = Engine(dict(seq_len=self.seq_len, vocab_size=self.vocab_size, bos_idx=self.bos_idx,
                                     det_feat_size=self.det_feat_size, input_encoding_size=self.input_encoding_size,
                                     rnn_size=self.rnn_size, att_size=self.att_size,
-                                    h2_first_lstm=int(self.h2_first_lstm), img_second_lstm=int(self.img_second_lstm)))
+                                    h2_first_lstm=int(self.h2_first_lstm), img_second_lstm=int(self.img_second_lstm)), device)
             self._verb_dev = None
+        if self.force_prepare:
+            self._eng.invalidate()
         params = {k: v.data for k, v in self.named_parameters()}
         pdev = next(iter(params.values())).device
         if pdev.type != 'cuda' or (device.index is not None and pdev.index != device.index):
@@ -102,11 +115,18 @@ class ControllableCaptioningModel(CaptioningModel):
     def _weights_version(self):
         return sum(p._version for p in self.parameters())
 
-    def _verbs(self, eng, verbs, device):
+    def _verbs(self, eng, verbs, device, rows=None, L=None):
+        if rows is not None and tuple(verbs.shape) != (rows, L):
+            raise RuntimeError("verb list statics[2] must have shape (rows, slots) = (%d, %d), got %s" % (rows, L, tuple(verbs.shape)))
         if self._verb_dev != device:
             eng.set_verb_table(self.verb_2_vob_all, device)
             self._verb_dev = device
         return verbs.to(device=device, dtype=torch.float32).contiguous()
+
+    @staticmethod
+    def _n_slots(regions):
+        from vsrcap.regions import IndexedRegions
+        return regions.slot_idx.size(1) if isinstance(regions, IndexedRegions) else regions.size(1)
 
     def _prepare(self, eng, det, regions, beam):
         """Hoisted per-image work for either region format: the reference's dense (B,L,R,D) tensor, or
@@ -132,12 +152,14 @@ class ControllableCaptioningModel(CaptioningModel):
         B = self._prepare(eng, det, ctrl_seq, 1)
         return eng.xe_forward(B, det.device, captions)
 
-    def _run_greedy(self, statics, verbs=None, gt=False):
+    def _run_greedy(self, statics):
+        """test() of the reference takes (detections, ctrl_det_seqs_test) only (:299); a third static (verb list) is an
+        extension that runs the greedy loop over step_v (gt=False) == beam_search_v with beam_size 1."""
         det, ctrl = statics[0], statics[1]
         eng = self._engine(det.device)
         B = self._prepare(eng, det, ctrl, 1)
-        v = self._verbs(eng, statics[2], det.device) if len(statics) > 2 and statics[2] is not None else None
-        return eng.greedy(B, det.device, v, gt)
+        v = self._verbs(eng, statics[2], det.device, B, self._n_slots(ctrl)) if len(statics) > 2 and statics[2] is not None else None
+        return eng.greedy(B, det.device, v, False)
 
     def _run_sample(self, statics, seed=None, forced=None):
         det, ctrl = statics[0], statics[1]
@@ -149,6 +171,11 @@ class ControllableCaptioningModel(CaptioningModel):
         B = self._prepare(eng, det, ctrl, 1)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            # data-parallel ranks that called torch.manual_seed(s) with the same s would otherwise draw IDENTICAL Gumbel /
+            # uniform noise for their shard rows (the Philox stream is keyed by (seed, local row, t))
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                seed ^= (dist.get_rank() + 1) << 48
         outs, lps = eng.sample(B, det.device, seed, forced)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from vsrcap.train import sample_logprobs_with_grad
@@ -159,7 +186,7 @@ class ControllableCaptioningModel(CaptioningModel):
         det, ctrl = statics[0], statics[1]
         eng = self._engine(det.device)
         B = self._prepare(eng, det, ctrl, beam_size)
-        v = self._verbs(eng, statics[2], det.device) if with_verbs else None
+        v = self._verbs(eng, statics[2], det.device, B, self._n_slots(ctrl)) if with_verbs else None
         (w, g), (lw, lg), _ = eng.beam(B, det.device, beam_size, out_size, eos_idxs[0], eos_idxs[1], v, gt)
         if out_size == 1:
             return [w[:, 0], g[:, 0]], [lw[:, 0], lg[:, 0]]
@@ -185,8 +212,8 @@ class ControllableCaptioningModel(CaptioningModel):
             outs, (s1, s2, _) = eng.step(1, 1, prev, ((h1, c1), (h2, c2), torch.zeros_like(slot)))
             # feeding the ground-truth word as "previous output" with gate 0 on a single slot IS teacher forcing
             return outs, (s1, s2, slot)
-        self._prepare(eng, det, statics[1], 1)
-        v = self._verbs(eng, statics[2], det.device) if with_verbs else None
+        B = self._prepare(eng, det, statics[1], 1)
+        v = self._verbs(eng, statics[2], det.device, B, self._n_slots(statics[1])) if with_verbs else None
         return eng.step(t, 1, prev_outputs, state, v, gt)
 
     def test(self, detections, ctrl_det_seqs_test):

@@ -3,11 +3,25 @@ workspace and enqueues everything on torch's current HIP stream.  PyTorch is plu
 streams); all arithmetic happens in libvsrcap.so.
 """
 import ctypes as C
+import functools
+import os
 
 import numpy as np
 import torch
 
 from . import _lib
+
+
+def _on_device(fn):
+    """Run an Engine method with the handle's device current: launches go to torch.cuda.current_stream(dev), and HIP
+    wants that stream's device to be the current one (a model on cuda:1 used without torch.cuda.set_device(1))."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        if self.device is None:
+            return fn(self, *a, **kw)
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **kw)
+    return wrapped
 
 
 def _ptr(t):
@@ -22,13 +36,28 @@ def _f32(t, name):
     return t.contiguous()
 
 
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class Engine:
-    def __init__(self, dims):
-        """dims: dict with the vsr_dims fields."""
+    def __init__(self, dims, device=None):
+        """dims: dict with the vsr_dims fields; device: the torch cuda device this handle lives on (one handle per device)."""
         self.lib = _lib.load()
         self.dims = _lib.VsrDims(**dims)
         self.h = C.c_void_p()
-        _lib.check(self.lib.vsr_create(C.byref(self.dims), C.byref(self.h)))
+        self.device = torch.device(device) if device is not None else None
+        if self.device is not None and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(self.device) if self.device is not None else _Null():
+            _lib.check(self.lib.vsr_create(C.byref(self.dims), C.byref(self.h)))
+        # VSR_CHECK_IDS=1 (or eng.check_ids = True): after every call that takes word / slot / verb ids, read back the
+        # library's count of out-of-range ids and raise like nn.Embedding would (costs one stream synchronisation per call)
+        self.check_ids = os.environ.get("VSR_CHECK_IDS", "0") not in ("", "0")
         self._bound_ptrs = None
         self._ws = None
         self._prep_key = None
@@ -61,6 +90,22 @@ class Engine:
             self._cache_key = None
         return ptrs
 
+    def invalidate(self):
+        """Forget the cached prepare() / decode cache.  prepare() keys its cache on (data_ptr, tensor._version, shapes,
+        weights version): writes that do not bump _version (t.data.copy_, DLPack / custom-kernel writes into the same
+        buffer, p.data edits of the weights) are invisible to it - call this after such a write."""
+        self._prep_key = None
+        self._cache_key = None
+
+    def raise_on_bad_ids(self, device, who):
+        if not self.check_ids:
+            return
+        n = C.c_int32(0)
+        _lib.check(self.lib.vsr_bad_ids(self.h, C.byref(n), self._stream(device)))
+        if n.value:
+            raise IndexError("%s: %d word / slot / verb ids out of range (clamped on the device; nn.Embedding would raise)" % (who, n.value))
+
+    @_on_device
     def set_verb_table(self, table, device):
         """table: dict str(verb id) -> list of vocab ids (verb_2_vob_all of the reference)."""
         ids = [int(k) for k in table.keys()]
@@ -77,6 +122,7 @@ class Engine:
         _lib.check(self.lib.vsr_set_verb_table(self.h, _ptr(rp), _ptr(fl), n))
 
     # ------------------------------------------------------------------ decode cache (inference only)
+    @_on_device
     def decode_cache(self, device, weights_version, enable=True):
         """(Re)build the embedding-projection cache when the weights changed; enable=False drops it (training)."""
         key = (self._bound_ptrs, weights_version) if enable else None
@@ -93,6 +139,7 @@ class Engine:
         self._cache_key = key
 
     # ------------------------------------------------------------------ hoisted statics
+    @_on_device
     def prepare(self, det, regions, beam, weights_version=None):
         det = _f32(det, "detections")
         regions = _f32(regions, "region sequences")
@@ -118,6 +165,7 @@ class Engine:
         self._prep_key = key
         return B
 
+    @_on_device
     def prepare_indexed(self, det, bank, slot_idx, row_img, beam, weights_version=None):
         """Index-list region format (include/vsrcap.h, vsr_prepare_indexed): det (n_img,R0,D), bank (n_img,Rb,D),
         slot_idx (B,L,R) int32 rows of the row's image bank (-1 = padding), row_img (B) int32 or None."""
@@ -158,6 +206,7 @@ class Engine:
         self._prep_key = key
         return B
 
+    @_on_device
     def row_mask(self, rows):
         """(n, D) fp32 GPU rows -> (n,) fp32 mask of rows whose sum is not zero (the reference's zero-row test)."""
         rows = _f32(rows, "rows")
@@ -166,6 +215,7 @@ class Engine:
         _lib.check(self.lib.vsr_row_mask(_ptr(flat), flat.size(0), flat.size(1), _ptr(out), self._stream(rows.device)))
         return out.reshape(rows.shape[:-1])
 
+    @_on_device
     def reorder_slots(self, slot_idx, rank, verbs, bank_mask, row_img, Rb):
         """eval_coco.py:222-241 on index lists (vsr_reorder_slots): returns (slot_idx_out, verbs_out or None)."""
         N, L, R = slot_idx.shape
@@ -179,6 +229,7 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     # ------------------------------------------------------------------ training (forward with saves + BPTT backward)
+    @_on_device
     def train_forward(self, B, device, word_in, slots=None):
         T = word_in.size(1)
         V = self.dims.vocab_size
@@ -194,10 +245,23 @@ class Engine:
         gate = torch.empty(B, T, 2, dtype=torch.float32, device=device)
         _lib.check(self.lib.vsr_train_forward(self.h, _ptr(word_in), _ptr(slots), T, _ptr(out), _ptr(gate), _ptr(self._tws),
                                               self._tws.numel(), self._stream(device)))
+        self.raise_on_bad_ids(device, "train_forward")
         return out, gate
 
-    def train_backward(self, device, grad_out, grad_gate, shapes):
-        """shapes: list of the 28 parameter shapes in WEIGHT_FIELDS order -> list of gradient tensors."""
+    def train_generation(self):
+        """identity of the forward pass saved in the handle (0 = none): see vsr_train_generation in include/vsrcap.h"""
+        return int(self.lib.vsr_train_generation(self.h))
+
+    @_on_device
+    def train_backward(self, device, grad_out, grad_gate, shapes, generation=None):
+        """shapes: list of the 28 parameter shapes in WEIGHT_FIELDS order -> list of gradient tensors.
+        generation: train_generation() recorded right after the forward this backward belongs to."""
+        if generation is not None and generation != self.train_generation():
+            raise RuntimeError(
+                "backward of a forward pass whose saved activations are gone: the handle keeps ONE training forward at a "
+                "time (a later forward / sample_rl(grad) / prepare() on this model replaced it, or this graph was already "
+                "differentiated into a new forward). Call backward() before the next forward, or accumulate gradients "
+                "over separate forward+backward pairs instead of loss = l1 + l2.")
         grad_out = _f32(grad_out, "grad of word log-probs")
         grad_gate = _f32(grad_gate, "grad of gate log-probs")
         grads = [torch.empty(s, dtype=torch.float32, device=device) for s in shapes]
@@ -205,6 +269,7 @@ class Engine:
         _lib.check(self.lib.vsr_train_backward(self.h, _ptr(grad_out), _ptr(grad_gate), C.byref(g), self._stream(device)))
         return grads
 
+    @_on_device
     def debug_buffer(self, name, shape, device):
         out = torch.empty(shape, dtype=torch.float32, device=device)
         _lib.check(self.lib.vsr_debug_copy(self.h, name.encode(), _ptr(out), out.numel(), self._stream(device)))
@@ -218,19 +283,24 @@ class Engine:
     def profile_seen(self):
         return int(self.lib.vsr_profile_seen(self.h))
 
+    @_on_device
     def profile_end(self, device):
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         _lib.check(self.lib.vsr_profile_end(self.h, self._stream(device), C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
 
     # ------------------------------------------------------------------ loops
+    @_on_device
     def greedy(self, B, device, verbs=None, gt=False):
         T = self.dims.seq_len
         words = torch.empty(B, T, dtype=torch.int64, device=device)
         gates = torch.empty(B, T, dtype=torch.int64, device=device)
         _lib.check(self.lib.vsr_greedy(self.h, _ptr(verbs), int(gt), _ptr(words), _ptr(gates), self._stream(device)))
+        if verbs is not None:
+            self.raise_on_bad_ids(device, "greedy (verbs)")
         return words, gates
 
+    @_on_device
     def sample(self, B, device, seed, forced=None):
         T = self.dims.seq_len
         words = torch.empty(B, T, dtype=torch.int64, device=device)
@@ -243,8 +313,11 @@ class Engine:
             fg = forced[1].to(device=device, dtype=torch.int64).contiguous()
         _lib.check(self.lib.vsr_sample(self.h, C.c_uint64(seed), _ptr(fw), _ptr(fg), _ptr(words), _ptr(gates), _ptr(lpw),
                                        _ptr(lpg), self._stream(device)))
+        if forced is not None:
+            self.raise_on_bad_ids(device, "sample (forced ids)")
         return (words, gates), (lpw, lpg)
 
+    @_on_device
     def beam(self, B, device, beam, out_size, eos_word, eos_gate, verbs=None, gt=False):
         T = self.dims.seq_len
         words = torch.empty(B, out_size, T, dtype=torch.int64, device=device)
@@ -254,8 +327,11 @@ class Engine:
         scores = torch.empty(B, out_size, dtype=torch.float32, device=device)
         _lib.check(self.lib.vsr_beam(self.h, beam, out_size, int(eos_word), int(eos_gate), _ptr(verbs), int(gt), _ptr(words),
                                      _ptr(gates), _ptr(lpw), _ptr(lpg), _ptr(scores), self._stream(device)))
+        if verbs is not None:
+            self.raise_on_bad_ids(device, "beam (verbs)")
         return (words, gates), (lpw, lpg), scores
 
+    @_on_device
     def xe_forward(self, B, device, captions):
         T = captions.size(1)
         V = self.dims.vocab_size
@@ -263,8 +339,10 @@ class Engine:
         out = torch.empty(B, T, V, dtype=torch.float32, device=device)
         gate = torch.empty(B, T, 2, dtype=torch.float32, device=device)
         _lib.check(self.lib.vsr_xe_forward(self.h, _ptr(captions), T, _ptr(out), _ptr(gate), self._stream(device)))
+        self.raise_on_bad_ids(device, "xe_forward")
         return out, gate
 
+    @_on_device
     def step(self, t, rows_per_image, prev, state, verbs=None, gt=False):
         (h1, c1), (h2, c2), slot = state
         dev = h1.device
@@ -282,4 +360,5 @@ class Engine:
         _lib.check(self.lib.vsr_step(self.h, t, rows_per_image, _ptr(pw), _ptr(pg), _ptr(h1), _ptr(c1), _ptr(h2), _ptr(c2),
                                      _ptr(slot), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(slot_out),
                                      _ptr(verbs), int(gt), _ptr(lw), _ptr(lg), self._stream(dev)))
+        self.raise_on_bad_ids(dev, "step")
         return (lw, lg), ((outs[0], outs[1]), (outs[2], outs[3]), slot_out)

@@ -17,6 +17,7 @@ class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, B, device, word_in, slots, *params):
         out, gate = eng.train_forward(B, device, word_in, slots)
+        ctx.generation = eng.train_generation()    # the handle keeps ONE saved forward: backward checks it is still this one
         ctx.eng = eng
         ctx.device = device
         ctx.shapes = [tuple(p.shape) for p in params]
@@ -30,7 +31,7 @@ class _DecoderFn(torch.autograd.Function):
             g_out = torch.zeros_like(out)
         if g_gate is None:
             g_gate = torch.zeros_like(gate)
-        grads = ctx.eng.train_backward(ctx.device, g_out.contiguous(), g_gate.contiguous(), ctx.shapes)
+        grads = ctx.eng.train_backward(ctx.device, g_out.contiguous(), g_gate.contiguous(), ctx.shapes, ctx.generation)
         return (None, None, None, None, None) + tuple(grads)
 
 
