@@ -1,81 +1,135 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the VSR captioning decoder hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload beam5|greedy] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload beam5|beam5idx|greedy|xe|scst]
+                    [--scaling weak|strong] [--dtype f32|bf16] [--no-cpu] [--no-secondary]
 
-Workload (BASELINE.json metric, configs[2]): beam-5 decode through ControllableCaptioningModel.beam_search,
-batch 100 images per GPU, 36 regions x 2048-d, 10 slots, seq_len 20, vocab 10 000, fp32 (the reference's
-precision; token parity holds in this mode).  A "step" = ONE full decode call on one batch of synthetic
-inputs already resident in HBM: hoisted statics (vsr_prepare) + 20 timesteps + back-tracking.
-tokens/s = n_gpus * B * T * steps / wall time (top-1 hypothesis tokens).
-Multi-GPU: images are independent, each rank decodes its own batch with its own weight replica, no
-data-path collective (weak scaling); only the timing is reduced (MAX over ranks).
+Headline (BASELINE.json metric, configs[2]): beam-5 decode through ControllableCaptioningModel.beam_search, batch 100
+images per GPU, 36 regions x 2048-d, 10 slots, seq_len 20, vocab 10 000, fp32 (the reference's precision; token parity
+holds in this mode).  A "step" = ONE full decode call on one batch of synthetic inputs already resident in HBM: hoisted
+statics (vsr_prepare) + 20 timesteps + back-tracking.  tokens/s = B_total * T * steps / wall time (top-1 hypothesis
+tokens).  The default line also carries the second half of the BASELINE metric as "secondary": the XE
+training step (configs[3] shapes; forward + NLL losses + hand-written BPTT + Adam [+ RCCL gradient all-reduce]).
+
+Multi-GPU (one process per GPU, RCCL):  `--gpus N` with no torch.distributed environment starts the N ranks itself
+(child processes; the parent never touches the GPU); under `python -m torch.distributed.run` each process is a rank.
+  --scaling weak    every rank owns a batch of 100 (decode: no data-path collective; XE: gradient all-reduce)
+  --scaling strong  ONE batch of 100 split 13,13,13,13,12,12,12,12 (parallel.shard_bounds); decode gathers the ids
+The timed region is bracketed by barrier + synchronize on both sides; the time is the MAX over ranks.
 """
 import argparse
 import json
 import os
+import platform
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "vsr-guided-cic_amd"))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-from vsrcap import synth  # noqa: E402
-
 CFG = dict(V=10000, B=100, R0=36, R=36, D=2048, L=10, T=20, E=1000, H=1000, A=512)
 BEAM = 5
 EOS = 3
 PROFILE_EVERY = 5
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense, spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 (never the 2:1-sparsity figure)
+PEAK_HBM_GBS = 8000.0
 
 
-def measured_traffic():
-    """HBM bytes per GEMM launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same
-    command, FETCH_SIZE doubled per the guide's gfx950 correction); None when no profile has been committed."""
-    best = None
+# ---------------------------------------------------------------------------------------------- rank launch
+def launch_ranks(args):
+    """Parent of a `--gpus N` run outside torch.distributed.run: start N rank processes and relay rank 0's line.
+    Nothing here initialises the GPU (no HIP call, no torch.cuda.*): the children do."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+def traffic_from_profiles(kind):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE on this same command, FETCH_SIZE doubled per the guide's gfx950 correction).  Returns (bytes, file):
+    the figure is QUOTED from that file, not measured in this run (PMC collection needs rocprofv3 around the process)."""
     pdir = os.path.join(ROOT, "profiles")
+    best = (None, None)
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
-            if f.endswith("gemm_hbm_traffic.json"):
+            if f.endswith(kind + "_hbm_traffic.json"):
                 try:
-                    best = json.load(open(os.path.join(pdir, f)))["hbm_bytes_per_launch"]
+                    best = (json.load(open(os.path.join(pdir, f)))["hbm_bytes_per_launch"], "profiles/" + f)
                 except Exception:
                     pass
     return best
 
 
-def cpu_baseline(weights, sample_B, beam):
-    """The CPU oracle in its as-written flavour (the reference's cost profile: per-step recompute of the pooled
-    descriptor / region projection, statics re-gather per beam step, full sort) on a bounded sample."""
+def cpu_info():
+    model = platform.processor() or "unknown"
+    phys = set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                pid = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or os.cpu_count() or 1)
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline legs
+def cpu_baseline(weights, sample_B, beam, torch, synth):
+    """the CPU oracle (PyTorch CPU, fp32) on a bounded sample of the same synthetic workload, in
+    the reference's AS-WRITTEN op order (per-step recompute of the pooled descriptor / region projection, statics
+    re-gather per beam step, full sort) - the number of record - and HOISTED beside it.  torch.set_num_threads(physical
+    cores); 1 warm-up call, median of 3 timed calls each."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vsr_oracle as vo
     c = CFG
-    o = vo.Oracle(weights, c["T"], 2, as_written=True)
+    model, cores = cpu_info()
+    torch.set_num_threads(cores)
     det = torch.from_numpy(synth.make_detections(sample_B, c["R0"], c["D"], seed=77))
     ctrl = torch.from_numpy(synth.make_ctrl(sample_B, c["L"], c["R"], c["D"], seed=77))
-    with torch.no_grad():
-        if beam > 1:
-            o.beam_search(det[:2], ctrl[:2], [EOS, -1], beam, 1)          # warm-up
-            t0 = time.time()
-            o.beam_search(det, ctrl, [EOS, -1], beam, 1)
-        else:
-            o.test(det[:2], ctrl[:2])
-            t0 = time.time()
-            o.test(det, ctrl)
-        dt = time.time() - t0
-    return dict(value=sample_B * c["T"] / dt, unit="tokens/s", cores=torch.get_num_threads(), kind="port",
-                sample="oracle/vsr_oracle.py as_written, %s, %d images x %d steps, fp32, %.1f s" %
-                       ("beam-%d" % beam if beam > 1 else "greedy", sample_B, c["T"], dt))
+    out = {}
+    for flavour in ("as_written", "hoisted"):
+        o = vo.Oracle(weights, c["T"], 2, as_written=flavour == "as_written")
+        run = (lambda d, r: o.beam_search(d, r, [EOS, -1], beam, 1)) if beam > 1 else (lambda d, r: o.test(d, r))
+        ts = []
+        with torch.no_grad():
+            run(det[:2], ctrl[:2])
+            for _ in range(3):
+                t0 = time.time()
+                run(det, ctrl)
+                ts.append(time.time() - t0)
+        out[flavour] = (sample_B * c["T"] / sorted(ts)[1], sorted(ts)[1])
+    return dict(value=out["as_written"][0], unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+                cpu_model=model, torch=torch.__version__, hoisted_value=out["hoisted"][0],
+                sample="oracle/vsr_oracle.py, %s, %d images x %d steps, fp32; as-written (the reference's op order) median of 3 = "
+                       "%.1f s per call, hoisted variant %.1f s; 1 warm-up call each" %
+                       ("beam-%d" % beam if beam > 1 else "greedy", sample_B, c["T"], out["as_written"][1], out["hoisted"][1]))
 
 
-def cpu_baseline_xe(weights, sample_B):
+def cpu_baseline_xe(weights, sample_B, torch, synth):
     """XE step of coco_scripts/train.py:103-113 on the CPU oracle (autograd backward + Adam), bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vsr_oracle as vo
     c = CFG
+    model, cores = cpu_info()
+    torch.set_num_threads(cores)
     o = vo.Oracle(weights, c["T"], 2, as_written=True)
     params = [o.p[k].requires_grad_(True) for k in o.p]
     opt = torch.optim.Adam(params, lr=5e-4)
@@ -84,58 +138,202 @@ def cpu_baseline_xe(weights, sample_B):
     caps = torch.from_numpy(synth.make_captions(sample_B, c["T"], c["V"], seed=77))
     gts = torch.from_numpy(synth.make_gate_gts(sample_B, c["T"], seed=77))
     ts = []
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.time()
         opt.zero_grad()
         out, gate = o.forward(det, caps, seq)
         vo.xe_loss(out, gate, caps, gts)[0].backward()
         opt.step()
         ts.append(time.time() - t0)
-    return dict(value=sample_B / ts[-1], unit="samples/s", cores=torch.get_num_threads(), kind="port",
+    med = sorted(ts[1:])[0]
+    return dict(value=sample_B / med, unit="samples/s", cores=torch.get_num_threads(), kind="port", cpu_model=model,
+                torch=torch.__version__,
                 sample="oracle/vsr_oracle.py as_written XE step (forward + NLL losses + autograd backward + Adam), %d images x %d steps, "
-                       "fp32, %.1f s (second of two steps)" % (sample_B, c["T"], ts[-1]))
+                       "fp32, %.1f s (best of two steps after one warm-up step)" % (sample_B, c["T"], med))
 
 
-def train_bench(args):
-    """XE step (BASELINE configs[3]) / SCST step (configs[4]) in fp32: forward + losses + hand-written BPTT backward +
-    Adam, data-parallel over ranks with RCCL gradient all-reduce and global loss normalisation (vsrcap/parallel.py)."""
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+# ---------------------------------------------------------------------------------------------- shared pieces
+class Dist:
+    def __init__(self, torch, dist):
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device("cuda", self.local_rank))
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_time(self, dt):
+        if self.world > 1:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def observed_world(self):
+        """what RCCL itself sees: the sum of a ones-vector over the ranks"""
+        if self.world == 1:
+            return 1
+        t = self.torch.ones(1, device=self.dev)
+        self.dist.all_reduce(t)
+        return int(t.item())
+
+
+def make_model(torch, synth, dev, train, dtype):
     from models import ControllableCaptioningModel
-    from vsrcap import parallel
     c = CFG
-    weights = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=0, gains={k: 1.0 for k in synth.DEFAULT_GAINS})
+    gains = {k: 1.0 for k in synth.DEFAULT_GAINS} if train else None
+    weights = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=0, gains=gains)
     m = ControllableCaptioningModel(c["T"], c["V"], 2, det_feat_size=c["D"], input_encoding_size=c["E"], rnn_size=c["H"],
                                     att_size=c["A"], verb_2_vob_all={})
     m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
-    m = m.to(dev).train()
-    opt = torch.optim.Adam(m.parameters(), lr=5e-4, fused=True)      # train.py:77 Adam(lr=5e-4); one fused launch per step instead of ~40 foreach kernels
-    xe = args.workload == "xe"
+    m = m.to(dev)
+    m = m.train() if train else m.eval()
+    if dtype != "f32":
+        m.set_compute_dtype(dtype)
+    return m, weights
+
+
+def roofline_block(dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic=None, traffic_source=None):
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    r = {"bound": "mfma",
+         "kernel": "gemm_nt_f32_kernel / gemm_tn_f32_small_kernel (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)" if dtype == "f32"
+                   else "gemm_nt_bf16_kernel (v_mfma_f32_32x32x16_bf16)",
+         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+         "launches": gemm_seen, "launches_timed": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
+         "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt,
+         "algorithmic_flops_per_launch": gemm_flops / max(gemm_n, 1)}
+    if traffic_source:
+        r["traffic_source"] = traffic_source + " (quoted from the committed rocprofv3 PMC passes of this command, not re-measured in this run)"
+    return r
+
+
+# ---------------------------------------------------------------------------------------------- decode
+def decode_bench(args, D, torch, dist, synth):
+    from vsrcap import parallel
+    c = CFG
+    dev, rank, world = D.dev, D.rank, D.world
+    m, weights = make_model(torch, synth, dev, False, args.dtype)
+    beam = BEAM if args.workload in ("beam5", "beam5idx") else 1
+    indexed = args.workload == "beam5idx"
+    strong = args.scaling == "strong" and world > 1
+    lo, hi = parallel.shard_bounds(c["B"], world, rank) if strong else (0, c["B"])
+    # two distinct resident batches, alternated, so no step can reuse the previous step's prepare()
+    batches = []
+    for i in range(2):
+        seed = 1000 + i + (0 if strong else 10 * rank)
+        if indexed:
+            # index-list region format (SURVEY 8f N2): the slots name rows of the image's own detection matrix
+            from vsrcap.regions import IndexedRegions
+            det = torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed, min_valid=c["R0"])[lo:hi]).to(dev)
+            idx = torch.from_numpy(synth.make_slot_indices(c["B"], c["L"], c["R"], c["R0"], seed=seed)[lo:hi]).contiguous().to(dev)
+            batches.append((det, IndexedRegions(det, idx)))
+        else:
+            batches.append((torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev),
+                            torch.from_numpy(synth.make_ctrl(c["B"], c["L"], c["R"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev)))
+
+    def one_step(i):
+        det, ctrl = batches[i & 1]
+        with torch.no_grad():
+            if beam > 1:
+                (w, g), _ = m.beam_search((det, ctrl), [EOS, -1], beam, 1)
+            else:
+                w, g = m.test(det, ctrl)
+            if strong:      # the one exchange of a sharded decode: (B, T) ids of every shard
+                w = parallel.gather_ids(w, c["B"])
+            return w
+
+    for i in range(args.warmup):
+        one_step(i)
+    eng = m._engine(dev)
+    D.barrier()
+    # HIP events around every 5th GEMM launch of the timed region (3 launch kinds per timestep: every kind is sampled
+    # equally often); an event pair on EVERY launch costs the timed region 3 %
+    eng.profile_begin(every=PROFILE_EVERY)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    D.barrier()
+    dt = time.perf_counter() - t0
+    gemm_seen = eng.profile_seen()
+    gemm_ms, gemm_n, gemm_flops = eng.profile_end(dev)
+    dt = D.max_time(dt)
+    images = c["B"] if strong else world * c["B"]
+    name = "beam-5" if beam > 1 else "greedy"
+    traffic, tsrc = traffic_from_profiles("gemm") if (beam > 1 and not indexed and args.dtype == "f32") else (None, None)
+    line = {
+        "metric": ("decoded tokens/sec at batch=100, beam=5, 36x2048 regions" + (", index-list region format" if indexed else ""))
+                  if beam > 1 else "decoded tokens/sec, greedy, batch=100, 36x2048 regions",
+        "value": images * c["T"] * args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "%s decode, batch %s, 36 regions x 2048-d, 10 slots, seq_len 20, vocab 10000 (BASELINE configs[%d])" %
+                               (name, "100 images split over the ranks (13/12 per GPU at 8)" if strong else "100 images/GPU", 2 if beam > 1 else 1),
+                   "beam": beam, "batch_per_gpu": hi - lo, "seq_len": c["T"],
+                   "parallelism": "images sharded, dp%d%s" % (world, ", ids all-gathered (RCCL)" if strong else ", no data-path collective"),
+                   "rccl_world_size_observed": D.observed_world(),
+                   "decode_cache": "prebuilt, weight-only (embedding rows through the x columns of the LSTM1 / gate input weights, "
+                                   "240 MB, built once per weight version outside the timed call; all per-image hoisting is inside)"},
+        "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic, tsrc),
+    }
+    if indexed and rank == 0:
+        dense = [(d, r.dense().contiguous()) for d, r in batches]
+        with torch.no_grad():
+            for i in range(2):
+                m.beam_search(dense[i & 1], [EOS, -1], beam, 1)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                m.beam_search(dense[i & 1], [EOS, -1], beam, 1)
+            torch.cuda.synchronize(dev)
+        line["config"]["dense_format_same_data_tokens_per_s"] = (hi - lo) * c["T"] * args.steps / (time.perf_counter() - t1)
+        line["config"]["region_bytes_per_batch"] = {"index_lists": int(batches[0][1].slot_idx.numel() * 4), "dense": int(dense[0][1].numel() * 4)}
+    del m, batches
+    torch.cuda.empty_cache()
+    return line, weights, beam
+
+
+# ---------------------------------------------------------------------------------------------- training
+def train_bench(args, D, torch, dist, synth, steps, warmup):
+    """XE step (BASELINE configs[3]) / SCST step (configs[4]): forward + losses + hand-written BPTT backward + Adam,
+    data-parallel over ranks with RCCL gradient all-reduce overlapped with the weight-gradient phase and global loss
+    normalisation (vsrcap/parallel.py)."""
+    from vsrcap import parallel
+    c = CFG
+    dev, rank, world = D.dev, D.rank, D.world
+    m, weights = make_model(torch, synth, dev, True, args.dtype)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4, fused=True)      # train.py:77 Adam(lr=5e-4); one fused launch per step
+    xe = args.workload != "scst"
+    strong = args.scaling == "strong" and world > 1
+    lo, hi = parallel.shard_bounds(c["B"], world, rank) if strong else (0, c["B"])
     L = c["T"] if xe else c["L"]
     batches = []
     for i in range(2):
-        seed = 2000 + 10 * rank + i
-        batches.append((torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed)).to(dev),
-                        torch.from_numpy(synth.make_ctrl(c["B"], L, c["R"], c["D"], seed=seed)).to(dev),
-                        torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed)).to(dev),
-                        torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed)).to(dev)))
-    step = parallel.DataParallelStep(list(m.parameters()), opt, forward_fn=lambda d, cp, sq: m((d,), (cp, sq)),
+        seed = 2000 + i + (0 if strong else 10 * rank)
+        batches.append((torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev),
+                        torch.from_numpy(synth.make_ctrl(c["B"], L, c["R"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev),
+                        torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed)[lo:hi]).contiguous().to(dev),
+                        torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed)[lo:hi]).contiguous().to(dev)))
+    step = parallel.DataParallelStep(m, opt, forward_fn=lambda d, cp, sq: m((d,), (cp, sq)),
                                      sample_fn=lambda d, ct: m.sample_rl(d, ct))
     NS = 5                          # samples per image (BASELINE configs[4]); the reference has no such loop, the caller
     rl_batches = []                 # repeats every image NS times (SURVEY 8a A6)
     if not xe:
         for det, reg, _, _ in batches:
             rl_batches.append((det.repeat_interleave(NS, 0).contiguous(), reg.repeat_interleave(NS, 0).contiguous()))
-
-    # rewards: per-sample CIDEr-D on the device (vsrcap/reward.py, SURVEY 8f N3; train.py:169-170) of the sampled / greedy
-    # captions against the batch's synthetic reference caption, document frequencies from a synthetic corpus of 2 000 captions
-    if not xe:
+        # rewards: per-sample CIDEr-D on the device (vsrcap/reward.py, SURVEY 8f N3; train.py:169-170) of the sampled /
+        # greedy captions against the batch's synthetic reference caption, document frequencies from a synthetic corpus
         from vsrcap.reward import CiderD, clean_ids
         corpus = [[clean_ids(cap, eos=EOS)] for cap in synth.make_captions(2000, c["T"], c["V"], seed=77)]
         cider = CiderD(corpus, c["V"])
@@ -154,49 +352,37 @@ def train_bench(args):
         det5, reg5 = rl_batches[i & 1]
         return step.scst_step(det5, reg5, lambda words: (cider.rewards(words, refs5[i & 1], EOS), r_base))
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for i in range(args.warmup):
+    for i in range(warmup):
         one_step(i)
     eng = m._engine(dev)
-    barrier()
+    D.barrier()
     eng.profile_begin(every=PROFILE_EVERY)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         one_step(i)
-    barrier()
+    D.barrier()
     dt = time.perf_counter() - t0
     gemm_seen = eng.profile_seen()
     gemm_ms, gemm_n, gemm_flops = eng.profile_end(dev)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if rank == 0:
-        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        line = {
-            "metric": "XE-step samples/sec" if xe else "SCST-step images/sec (5 samples/image + greedy baseline, CIDEr-D rewards on device)",
-            "value": world * c["B"] * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("XE training step (forward + NLL losses + BPTT backward + torch.optim.Adam(fused=True)), batch 100/GPU, 20 slots x 36 regions x 2048-d, "
-                                    "seq_len 20, vocab 10000 (BASELINE configs[3], fp32)") if xe else
-                                   ("SCST step: greedy baseline (100 images) + sample_rl on 500 rows (5 samples/image) + replayed forward + BPTT "
-                                    "backward + Adam(fused=True), rewards = device CIDEr-D vs synthetic references, 10 slots x 36 x 2048 (BASELINE configs[4], fp32)"),
-                       "batch_per_gpu": c["B"], "seq_len": c["T"], "parallelism": "dp%d, RCCL gradient all-reduce" % world},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "launches": gemm_seen, "launches_timed": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
-                         "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt},
-        }
-        if world == 1 and not args.no_cpu and xe:
-            line["cpu_baseline"] = cpu_baseline_xe(weights, min(args.cpu_sample, 16))
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+    dt = D.max_time(dt)
+    images = c["B"] if strong else world * c["B"]
+    line = {
+        "metric": "XE-step samples/sec" if xe else "SCST-step images/sec (5 samples/image + greedy baseline, CIDEr-D rewards on device)",
+        "value": images * steps / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": ("XE training step (forward + NLL losses + BPTT backward + torch.optim.Adam(fused=True)), batch %s, 20 slots x 36 regions x 2048-d, "
+                                "seq_len 20, vocab 10000 (BASELINE configs[3] shapes)" % ("100 split over the ranks" if strong else "100/GPU")) if xe else
+                               ("SCST step: greedy baseline (100 images) + sample_rl on 500 rows (5 samples/image) + replayed forward + BPTT "
+                                "backward + Adam(fused=True), rewards = device CIDEr-D vs synthetic references, 10 slots x 36 x 2048 (BASELINE configs[4])"),
+                   "batch_per_gpu": hi - lo, "seq_len": c["T"],
+                   "parallelism": "dp%d, RCCL gradient all-reduce in buckets on a side stream, overlapped with the weight-gradient GEMMs" % world,
+                   "rccl_world_size_observed": D.observed_world()},
+        "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt),
+    }
+    del m, opt, step, batches
+    torch.cuda.empty_cache()
+    return line, weights
 
 
 def main():
@@ -205,115 +391,43 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="beam5", choices=["beam5", "beam5idx", "greedy", "xe", "scst"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = parity mode (headline); bf16 = throughput mode (bf16 operands, fp32 accumulate, fp32 master weights)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=24)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the XE-step leg of the default line")
+    ap.add_argument("--cpu-sample", type=int, default=12)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import torch
+    import torch.distributed as dist
+    from vsrcap import synth
+    D = Dist(torch, dist)
+    if args.gpus != D.world and D.rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, D.world, D.world), file=sys.stderr)
+
     if args.workload in ("xe", "scst"):
-        return train_bench(args)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    from models import ControllableCaptioningModel
-    c = CFG
-    weights = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=0)
-    m = ControllableCaptioningModel(c["T"], c["V"], 2, det_feat_size=c["D"], input_encoding_size=c["E"], rnn_size=c["H"],
-                                    att_size=c["A"], verb_2_vob_all={})
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
-    m = m.to(dev).eval()
-    # two distinct resident batches per rank, alternated, so no step can reuse the previous step's prepare()
-    batches = []
-    for i in range(2):
-        seed = 1000 + 10 * rank + i
-        batches.append((torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed)).to(dev),
-                        torch.from_numpy(synth.make_ctrl(c["B"], c["L"], c["R"], c["D"], seed=seed)).to(dev)))
-    beam = BEAM if args.workload in ("beam5", "beam5idx") else 1
-    indexed = args.workload == "beam5idx"
-    if indexed:
-        # index-list region format: the slots name rows of the image's own detection matrix instead of
-        # carrying copies of them; same shapes as the headline workload, decoded through vsr_prepare_indexed
-        from vsrcap.regions import IndexedRegions
-        batches = []
-        for i in range(2):
-            seed = 1000 + 10 * rank + i
-            det = torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed, min_valid=c["R0"])).to(dev)
-            idx = torch.from_numpy(synth.make_slot_indices(c["B"], c["L"], c["R"], c["R0"], seed=seed)).to(dev)
-            batches.append((det, IndexedRegions(det, idx)))
-
-    def one_step(i):
-        det, ctrl = batches[i & 1]
-        with torch.no_grad():
-            if beam > 1:
-                return m.beam_search((det, ctrl), [EOS, -1], beam, 1)
-            return m.test(det, ctrl)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for i in range(args.warmup):
-        one_step(i)
-    eng = m._engine(dev)
-    barrier()
-    # HIP events around every 5th GEMM launch of the timed region (3 launch kinds per timestep: every kind is sampled
-    # equally often); an event pair on EVERY launch costs the timed region 3 % (192.3 k vs 198.7 k tokens/s without any)
-    eng.profile_begin(every=PROFILE_EVERY)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    gemm_seen = eng.profile_seen()
-    gemm_ms, gemm_n, gemm_flops = eng.profile_end(dev)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if rank == 0:
-        tokens = world * c["B"] * c["T"] * args.steps
-        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        line = {
-            "metric": ("decoded tokens/sec at batch=100, beam=5, 36x2048 regions" + (", index-list region format" if indexed else ""))
-                      if beam > 1 else "decoded tokens/sec, greedy, batch=100, 36x2048 regions",
-            "value": tokens / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s decode, batch 100 images/GPU, 36 regions x 2048-d, 10 slots, seq_len 20, vocab 10000 "
-                                   "(BASELINE configs[%d])" % ("beam-5" if beam > 1 else "greedy", 2 if beam > 1 else 1),
-                       "beam": beam, "batch_per_gpu": c["B"], "seq_len": c["T"], "parallelism": "images sharded, dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": measured_traffic() if (beam > 1 and not indexed) else None, "launches": gemm_seen,
-                         "launches_timed": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
-                         "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt,
-                         "algorithmic_flops_per_launch": gemm_flops / max(gemm_n, 1)},
-        }
-        if indexed:
-            # the same data through the dense wire format of the reference (regions materialised once, outside the timing)
-            dense = [(d, r.dense().contiguous()) for d, r in batches]
-            with torch.no_grad():
-                for i in range(2):
-                    m.beam_search(dense[i & 1], [EOS, -1], beam, 1)
-                torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-                for i in range(args.steps):
-                    m.beam_search(dense[i & 1], [EOS, -1], beam, 1)
-                torch.cuda.synchronize(dev)
-            line["config"]["dense_format_same_data_tokens_per_s"] = c["B"] * c["T"] * args.steps / (time.perf_counter() - t1)
-            line["config"]["region_bytes_per_batch"] = {"index_lists": int(batches[0][1].slot_idx.numel() * 4),
-                                                        "dense": int(dense[0][1].numel() * 4)}
-        if world == 1 and not args.no_cpu and not indexed:
-            line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam)
-        print(json.dumps(line))
-    if world > 1:
+        line, weights = train_bench(args, D, torch, dist, synth, args.steps, args.warmup)
+        if D.rank == 0 and D.world == 1 and not args.no_cpu and args.workload == "xe":
+            line["cpu_baseline"] = cpu_baseline_xe(weights, min(args.cpu_sample, 16), torch, synth)
+    else:
+        line, weights, beam = decode_bench(args, D, torch, dist, synth)
+        if args.workload == "beam5" and not args.no_secondary:
+            # the other half of BASELINE.json's metric in the same driver-timed run
+            xa = argparse.Namespace(**vars(args))
+            xa.workload = "xe"
+            xe_line, _ = train_bench(xa, D, torch, dist, synth, max(5, args.steps // 2), 2)
+            line["secondary"] = {k: xe_line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                         "scaling", "dtype", "config", "roofline")}
+        if D.rank == 0 and D.world == 1 and not args.no_cpu and args.workload != "beam5idx":
+            line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam, torch, synth)
+    if D.rank == 0:
+        print(json.dumps(line), flush=True)
+    if D.world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

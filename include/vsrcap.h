@@ -194,6 +194,13 @@ int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, const float*
  * a caller that may have several forwards alive (loss = l1 + l2, XE forward + sample_rl in one step, a second
  * backward) records the value after its forward and refuses to call vsr_train_backward when it has changed. */
 int64_t vsr_train_generation(const vsr_handle* h);
+/* Data-parallel hook (the reference is single-device, coco_scripts/train.py:22): vsr_train_backward finishes the
+ * 28 gradients in buckets, largest first, and records a HIP event after each.  bucket_of[i] = bucket of gradient i (field
+ * order of vsr_weights), static.  vsr_train_wait_bucket() makes `stream` wait on the device for one bucket of the LAST
+ * backward, so its all-reduce (RCCL, side stream) overlaps the remaining weight-gradient GEMMs.  The *grads pointers may
+ * point into one flat caller buffer laid out in bucket order: each bucket is then one contiguous collective. */
+int vsr_train_bucket_map(int32_t* bucket_of, int32_t* n_buckets);
+int vsr_train_wait_bucket(vsr_handle* h, int32_t bucket, void* stream);
 
 /* test hook: copy an internal buffer of the saved training pass ("dpre1", "dpre2", "dh2_voc", "gates1", ...) */
 int vsr_debug_copy(vsr_handle* h, const char* name, float* dst, size_t n_floats, void* stream);

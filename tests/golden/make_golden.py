@@ -15,6 +15,12 @@ Fixtures:
   g4_beam_v / g4_beam_v_small             verb-forced beam search, gt False / True
   g5_sample                               sample_rl draws of the reference + its log-probs (replay)
   g6_step                                 single step from a non-zero state, pointer at the clamp
+  g6_step_v                               the same through step_v with verb-forced rows, gt False / True
+  g1_xe_b100                              XE at batch 100, full size (BASELINE configs[3] shapes, fp32): losses, grad norms
+  g9_scst_500                             sample_rl on 500 rows (100 images x 5, configs[4]): the reference's draws and
+                                          log-probs; SCST gradient norms of a 40-row slice replaying those draws
+  g10_fresh                               2 FRESH seeds x 48 images (no margin search): reference greedy + beam-5 tokens,
+                                          fp64-oracle margins / agreement flags
 """
 import json
 import os
@@ -115,8 +121,9 @@ def pick_seed_and_greedy(c):
 
 
 def main():
-    """Stages are independent and resumable:  python tests/golden/make_golden.py [small] [greedy] [beam] [verbs] [sample]"""
-    stages = sys.argv[1:] or ["small", "greedy", "beam", "verbs", "sample"]
+    """Stages are independent and resumable:
+    python tests/golden/make_golden.py [small] [greedy] [beam] [verbs] [sample] [stepv] [xe100] [scst500] [fresh]"""
+    stages = sys.argv[1:] or ["small", "greedy", "beam", "verbs", "sample", "stepv", "xe100", "scst500", "fresh"]
     torch.manual_seed(0)
     tmp = tempfile.mkdtemp()
     os.makedirs(os.path.join(tmp, "datasets/coco"))
@@ -131,7 +138,17 @@ def main():
     set_table("small")
     if "small" in stages:
         stage_small(cS, cW, tables)
+    if "stepv" in stages:
+        stage_stepv(cS, tables)
     set_table("full")
+    if "xe100" in stages:
+        t0 = time.time()
+        xe_fixture("g1_xe_b100", cfg_full(100), {k: 1.0 for k in synth.DEFAULT_GAINS}, seed=7)
+        print("XE B=100 fixture %.1fs" % (time.time() - t0))
+    if "scst500" in stages:
+        stage_scst500()
+    if "fresh" in stages:
+        stage_fresh()
     cF = cfg_full(256)
     if "greedy" in stages:
         stage_greedy(cF)
@@ -194,6 +211,107 @@ def stage_small(cS, cW, tables):
     save("g6_step", dict(cfg=cS, seed=5, wseed=0, bos=BOS, t=3, k0=k0.tolist(), prev_w=prev[0].tolist(), prev_g=prev[1].tolist()),
          logp_w=lw.numpy(), logp_g=lg.numpy(), h1=s1[0].numpy(), c1=s1[1].numpy(), h2=s2[0].numpy(), c2=s2[1].numpy(),
          k=k1.numpy())
+
+
+def stage_stepv(cS, tables):
+    """G6-v: one feedback step through step_v (:192-297): rows with a verb at their slot (table entry with several ids,
+    with one id, verb without an entry -> id 0), a row without a verb, pointer at the clamp; gt False / True."""
+    m, w = build_ref(cS)
+    m.eval()
+    det, ctrl = inputs(cS, 5)
+    B, H, L = cS["B"], cS["H"], cS["L"]
+    st = [torch.from_numpy((synth.hash_u01(B * H, 50 + i, 9).reshape(B, H) - 0.5).astype(np.float32)) for i in range(4)]
+    k0 = torch.tensor([0, L - 2, L - 1, 1])
+    prev = (torch.tensor([5, 7, 11, 13]), torch.tensor([1, 1, 1, 0]))
+    # slots after the pointer update: [1, L-1, L-1, 1]
+    many = max(tables["small"], key=lambda k: len(tables["small"][k]))
+    one = min((k for k in tables["small"] if len(tables["small"][k]) > 0), key=lambda k: len(tables["small"][k]))
+    verbs = -torch.ones(B, L, dtype=torch.float64)           # eval_coco.py:240 hands a float64 tensor
+    verbs[0, 1] = float(many)
+    verbs[1, L - 1] = float(one)
+    verbs[2, L - 1] = float(NV + 3)                           # no table entry -> id 0 (:292)
+    arrays = {}
+    with torch.no_grad():
+        for gt in (False, True):
+            (lw, lg), (s1, s2, k1) = m.step_v(3, ((st[0], st[1]), (st[2], st[3]), k0), prev, (det, ctrl, verbs), None,
+                                              mode="feedback", gt=gt)
+            arrays["logp_w_gt%d" % gt] = lw.numpy()
+            arrays["logp_g_gt%d" % gt] = lg.numpy()
+            arrays["h2_gt%d" % gt] = s2[0].numpy()
+            arrays["k_gt%d" % gt] = k1.numpy()
+    save("g6_step_v", dict(cfg=cS, seed=5, wseed=0, bos=BOS, t=3, k0=k0.tolist(), prev_w=prev[0].tolist(), prev_g=prev[1].tolist(),
+                           verbs=verbs.tolist(), nv=NV, verb_table=tables["small"]), **arrays)
+
+
+def stage_scst500():
+    """configs[4]: sample_rl on 100 images x 5 samples = 500 rows (the caller repeats every image 5 times).
+    (1) the reference draws 500 x 20 samples (no grad) and returns their log-probs; (2) rows 0..39 replay exactly those
+    draws under autograd (Categorical.sample is patched IN THIS GENERATOR ONLY to hand back the recorded draws; the
+    reference's code runs unchanged) -> SCST loss of train.py:174-175 with closed-form rewards -> gradient norms."""
+    from torch import distributions
+    cF = cfg_full(100)
+    m, w = build_ref(cF)
+    m.eval()
+    det, ctrl = inputs(cF, 23)
+    det5, ctrl5 = det.repeat_interleave(5, 0).contiguous(), ctrl.repeat_interleave(5, 0).contiguous()
+    torch.manual_seed(4321)
+    t0 = time.time()
+    with torch.no_grad():
+        (sw, sg), (lw, lg) = m.sample_rl(det5, ctrl5)
+    print("reference sample_rl 500 rows: %.1fs" % (time.time() - t0))
+    n = 40
+    queue = []
+    for t in range(cF["T"]):
+        queue += [sw[:n, t].clone(), sg[:n, t].clone()]
+    real_sample = distributions.Categorical.sample
+    distributions.Categorical.sample = lambda self, *a, **k: queue.pop(0)
+    try:
+        m.train()
+        m.zero_grad()
+        (sw2, sg2), (lw2, lg2) = m.sample_rl(det5[:n].contiguous(), ctrl5[:n].contiguous())
+    finally:
+        distributions.Categorical.sample = real_sample
+    assert (sw2 == sw[:n]).all() and (sg2 == sg[:n]).all() and not queue
+    assert (lw2.detach() - lw[:n]).abs().max() < 1e-4
+    reward = torch.from_numpy(synth.hash_u01(n, 70, 1).astype(np.float32))
+    base = torch.from_numpy(synth.hash_u01(n, 71, 1).astype(np.float32))
+    loss = vo.scst_loss(lw2, lg2, reward, base)
+    loss.backward()
+    gnorm = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()], dtype=np.float64)
+    order = [k for k, _ in m.named_parameters()]
+    print("SCST slice loss %.6f, %.1fs" % (loss.item(), time.time() - t0))
+    save("g9_scst_500", dict(cfg=cF, seed=23, wseed=0, bos=BOS, torch_seed=4321, n_rep=5, n_slice=n, param_order=order,
+                             reward_hash=[70, 1], baseline_hash=[71, 1]),
+         words=sw.numpy().astype(np.int16), gates=sg.numpy().astype(np.int8), lp_w=lw.numpy(), lp_g=lg.numpy(),
+         slice_loss=np.array([loss.item()], dtype=np.float64), slice_grad_norm=gnorm)
+
+
+def stage_fresh():
+    """2 fresh input seeds (NOT searched for margins) x 48 images at full size: the reference's greedy and beam-5 tokens,
+    the fp64 oracle's greedy margins and its beam-5 agreement with the reference (rows where fp32 and fp64 disagree are
+    numerically ambiguous for ANY fp32 implementation and are reported, not asserted, by the test)."""
+    c = cfg_full(48)
+    m, w = build_ref(c)
+    m.eval()
+    o64 = vo.Oracle(w, c["T"], BOS, as_written=False, dtype=torch.float64)
+    arrays, seeds = {}, [901, 902]
+    for seed in seeds:
+        det, ctrl = inputs(c, seed)
+        t0 = time.time()
+        with torch.no_grad():
+            gw, gg = m.test(det, ctrl)
+            (bw, bg), _ = m.beam_search((det, ctrl), [3, -1], 5, 1)
+            w64, g64, marg, ks, _ = o64.test(det.double(), ctrl.double(), return_trace=True)
+            (ow, og), _, sc = o64.beam_search(det.double(), ctrl.double(), [3, -1], 5, 1, return_scores=True)
+        g_ok = (w64 == gw).all(1) & (g64 == gg).all(1)
+        b_ok = (ow == bw).all(1) & (og == bg).all(1)
+        print("seed %d: greedy ref==fp64 %d/48 (min margins %.2e / %.2e), beam ref==fp64 %d/48, %.0fs" %
+              (seed, int(g_ok.sum()), marg[:, :, 0].min().item(), marg[:, :, 1].min().item(), int(b_ok.sum()), time.time() - t0), flush=True)
+        arrays.update({"greedy_words_%d" % seed: gw.numpy().astype(np.int16), "greedy_gates_%d" % seed: gg.numpy().astype(np.int8),
+                       "beam_words_%d" % seed: bw.numpy().astype(np.int16), "beam_gates_%d" % seed: bg.numpy().astype(np.int8),
+                       "margins_%d" % seed: marg.numpy().astype(np.float32), "greedy_agree64_%d" % seed: g_ok.numpy(),
+                       "beam_agree64_%d" % seed: b_ok.numpy()})
+    save("g10_fresh", dict(cfg=c, seeds=seeds, wseed=0, bos=BOS, eos=[3, -1]), **arrays)
 
 
 def stage_greedy(cF):

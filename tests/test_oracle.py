@@ -119,6 +119,54 @@ def test_full_size_greedy_beam_sample_subset():
     assert g["margins"][:, :, 0].min() >= 1e-4 and g["margins"][:, :, 1].min() >= 2e-3
 
 
+def test_step_v_vector():
+    """G6-v: the verb-forced step (controllable_captioning.py:192-297), gt False / True, vs the reference's outputs."""
+    meta, g = load_golden("g6_step_v")
+    cfg = meta["cfg"]
+    o, _ = _oracle(meta, table=meta["verb_table"])
+    det, ctrl = helpers.decode_inputs(cfg, meta["seed"])
+    B, H = cfg["B"], cfg["H"]
+    st = [torch.from_numpy((synth.hash_u01(B * H, 50 + i, 9).reshape(B, H) - 0.5).astype(np.float32)) for i in range(4)]
+    prev = (torch.tensor(meta["prev_w"]), torch.tensor(meta["prev_g"]))
+    verbs = torch.tensor(meta["verbs"], dtype=torch.float64)
+    for flag in (False, True):
+        with torch.no_grad():
+            (lw, lg), s = o.step(meta["t"], st + [torch.tensor(meta["k0"])], prev, det, ctrl, verbs=verbs, gt=flag)
+        np.testing.assert_array_equal(s[4].numpy(), g["k_gt%d" % flag])
+        np.testing.assert_allclose(lw.numpy(), g["logp_w_gt%d" % flag], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(lg.numpy(), g["logp_g_gt%d" % flag], atol=1e-5, rtol=0)
+        np.testing.assert_allclose(s[2].numpy(), g["h2_gt%d" % flag], atol=1e-6, rtol=0)
+    assert ((g["logp_w_gt0"] == 0).sum(1) == 1).sum() == 3
+
+
+def test_scst_500_fixture_slice_and_fresh_seed_subset():
+    """configs[4] fixture: replaying the reference's draws through the oracle reproduces its log-probs (first 10 of the
+    500 rows; all 500 are replayed on the GPU box).  g10_fresh: first 6 images of a fresh seed, greedy + beam-5 tokens."""
+    meta, g = load_golden("g9_scst_500")
+    cfg = meta["cfg"]
+    o, _ = _oracle(meta)
+    det, ctrl = helpers.decode_inputs(cfg, meta["seed"], n=2)
+    det5, ctrl5 = det.repeat_interleave(meta["n_rep"], 0), ctrl.repeat_interleave(meta["n_rep"], 0)
+    n = det5.size(0)
+    fw, fg = torch.from_numpy(g["words"][:n].astype(np.int64)), torch.from_numpy(g["gates"][:n].astype(np.int64))
+    with torch.no_grad():
+        _, (lw, lg) = o.sample_rl(det5, ctrl5, forced=(fw, fg))
+    np.testing.assert_allclose(lw.numpy(), g["lp_w"][:n], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(lg.numpy(), g["lp_g"][:n], atol=1e-4, rtol=0)
+    assert len(np.unique(g["words"])) >= 200                       # the draws are diverse
+    meta, g = load_golden("g10_fresh")
+    seed = meta["seeds"][0]
+    o, _ = _oracle(meta)
+    det, ctrl = helpers.decode_inputs(meta["cfg"], seed, n=6)
+    with torch.no_grad():
+        w, gate = o.test(det, ctrl)
+        (bw, bg), _ = o.beam_search(det, ctrl, meta["eos"], 5, 1)
+    np.testing.assert_array_equal(w.numpy(), g["greedy_words_%d" % seed][:6])
+    np.testing.assert_array_equal(gate.numpy(), g["greedy_gates_%d" % seed][:6])
+    np.testing.assert_array_equal(bw.numpy(), g["beam_words_%d" % seed][:6])
+    np.testing.assert_array_equal(bg.numpy(), g["beam_gates_%d" % seed][:6])
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference not mounted (GPU box)")
 def test_live_against_reference(tmp_path, monkeypatch):
     import json

@@ -1,0 +1,35 @@
+#!/bin/bash
+# One gpurun call: GPU tests, the default bench line, kernel stats and PMC passes.  usage: tools/gpu_round.sh <tag> [what...]
+TAG=${1:-r02_a}; shift
+WHAT=${@:-tests bench stats pmc}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for w in $WHAT; do
+case $w in
+tests)
+  timeout 1500 python -m pytest tests -m gpu -q -rA --durations=15 > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -40 $OUT/pytest.log ;;
+bench)
+  timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"; cat $OUT/bench_default.json ;;
+greedy)
+  timeout 300 python bench.py --workload greedy --no-cpu > $OUT/bench_greedy.json 2> $OUT/bench_greedy.err; cat $OUT/bench_greedy.json ;;
+xe)
+  timeout 300 python bench.py --workload xe --no-cpu > $OUT/bench_xe.json 2> $OUT/bench_xe.err; cat $OUT/bench_xe.json ;;
+scst)
+  timeout 300 python bench.py --workload scst --no-cpu > $OUT/bench_scst.json 2> $OUT/bench_scst.err; cat $OUT/bench_scst.json ;;
+stats)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_beam5 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-secondary > $GRAFT_REPO_ROOT/$OUT/stats_beam5.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_xe -- python3 $GRAFT_REPO_ROOT/bench.py --workload xe --steps 5 --warmup 2 --no-cpu > $GRAFT_REPO_ROOT/$OUT/stats_xe.log 2>&1)
+  find $OUT -name "*kernel_stats.csv" | head; for f in $(find $OUT -name "*kernel_stats.csv"); do echo $f; head -25 $f; done
+  # keep only the stats (traces are large)
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
+pmc)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary > $GRAFT_REPO_ROOT/$OUT/pmc_$c.log 2>&1)
+  done
+  python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/gemm_hbm_traffic.json gemm_
+  python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/attend_hbm_traffic.json k_attend
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
+esac
+done
+du -sh $OUT

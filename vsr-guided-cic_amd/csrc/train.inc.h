@@ -12,7 +12,11 @@
 //            dW[n][k] = sum_rows dY^T[n][row] * X^T[k][row]   (both operands transposed once per call)
 // so every matrix product of the backward pass runs on the same stream-K fp32-MFMA kernel as the forward pass.
 
+constexpr int VSR_GRAD_BUCKETS = 5;
 struct TrainCtx {
+    hipEvent_t bucket_ev[VSR_GRAD_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // recorded by vsr_train_backward
+    bool buckets_recorded = false;
+    ~TrainCtx() { for (hipEvent_t e : bucket_ev) if (e) (void)hipEventDestroy(e); }
     bool valid = false;
     long long generation = 0;          // bumped by every vsr_train_forward: identifies the saved forward a backward belongs to
     int B = 0, T = 0, TB = 0, TBp = 0, Bp = 0, RLp = 0;
@@ -502,10 +506,24 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     transpose(s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
     LAUNCHCHK();
 
-    // out_fc
-    if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H)) return 1;
-    colsum(t, s, t.dlogits, (long long)Vp, TB, V, G[g_bout]);
-    // lstm_cell_2
+    // Gradients are finished bucket by bucket, largest first, and an event is recorded after each bucket
+    // (vsr_train_bucket_map / vsr_train_wait_bucket): a data-parallel caller starts the all-reduce of a finished bucket on
+    // a side stream while the remaining weight-gradient GEMMs run.  The last bucket is the smallest (14 MB).
+    if (!t.bucket_ev[0])
+        for (int i = 0; i < VSR_GRAD_BUCKETS; ++i) HIPCHK(hipEventCreateWithFlags(&t.bucket_ev[i], hipEventDisableTiming));
+    // ---- bucket 0: lstm_cell_1.weight_ih / W1_is / W1_ig: row blocks [0,4H), [4H,5H), [5H,6H) of dpre1^T against [h2_prev | vbar | x]
+    {
+        float* Gw[3] = {G[g_Wih1], G[g_Wis], G[g_Wig]};
+        const int r0[3] = {0, 4 * H, 5 * H}, nr[3] = {4 * H, H, H};
+        for (int i = 0; i < 3; ++i) {
+            const float* dy = t.tY_dpre1 + (size_t)r0[i] * TBp;
+            if (d.h2_first_lstm && gemm_to1(h, t, s, nr[i], H, TBp, dy, TBp, t.tX_h2prev, TBp, Gw[i], in1)) return 1;
+            if (gemm_to1(h, t, s, nr[i], D, Bp, t.tY_dpre1sum + (size_t)r0[i] * Bp, Bp, t.tX_vbar, Bp, Gw[i] + voff, in1)) return 1;
+            if (gemm_to1(h, t, s, nr[i], E, TBp, dy, TBp, t.tX_x, TBp, Gw[i] + xoff, in1)) return 1;
+        }
+    }
+    HIPCHK(hipEventRecord(t.bucket_ev[0], s));
+    // ---- bucket 1: lstm_cell_2
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2)) return 1;
     if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2)) return 1;
     if (d.img_second_lstm) {
@@ -516,52 +534,79 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H)) return 1;
     colsum(t, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2]);
     HIPCHK(hipMemcpyAsync(G[g_bhh2], G[g_bih2], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    // att_ga, W1_hg, att_ha, s_fc, att_sa
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H)) return 1;
-    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H)) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H)) return 1;
+    HIPCHK(hipEventRecord(t.bucket_ev[1], s));
+    // ---- bucket 2: out_fc and the embedding
+    if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H)) return 1;
+    colsum(t, s, t.dlogits, (long long)Vp, TB, V, G[g_bout]);
+    {   // embedding: dx = dpre1 . [W_ih1 ; W_is ; W_ig][:, x columns], summed onto the rows that were looked up (ordered, no atomics)
+        SegSpec sg[3] = {{t.dpre1, 6 * H, t.wT_ih1 + (size_t)xoff * 4 * H, 4 * H, 4 * H},
+                         {t.dpre1 + 4 * H, 6 * H, t.wT_is + (size_t)xoff * H, H, H},
+                         {t.dpre1 + 5 * H, 6 * H, t.wT_ig + (size_t)xoff * H, H, H}};
+        if (gemm_to(h, t, s, TB, E, sg, 3, t.dx_all, E)) return 1;
+        HIPCHK(hipMemsetAsync(G[g_embed], 0, (size_t)V * E * sizeof(float), s));
+        hipLaunchKernelGGL(k_embed_grad_rows, dim3(TB), dim3(256), 0, s, t.dx_all, t.word32, TB, E, G[g_embed]);
+    }
+    HIPCHK(hipEventRecord(t.bucket_ev[2], s));
+    // ---- bucket 3: the recurrent LSTM1 / sentinel-gate weights, all LSTM1 / gate biases, s_fc, att_va
+    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H)) return 1;
+    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H)) return 1;
+    colsum(t, s, t.dpre1, (long long)6 * H, TB, 4 * H, G[g_bih1]);
+    HIPCHK(hipMemcpyAsync(G[g_bhh1], G[g_bih1], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    colsum(t, s, t.dpre1 + 4 * H, (long long)6 * H, TB, H, G[g_bis]);
+    HIPCHK(hipMemcpyAsync(G[g_bhs], G[g_bis], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    colsum(t, s, t.dpre1 + 5 * H, (long long)6 * H, TB, H, G[g_big]);
+    HIPCHK(hipMemcpyAsync(G[g_bhg], G[g_big], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (gemm_to1(h, t, s, D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H)) return 1;
     colsum(t, s, t.dsent_all, (long long)D, TB, D, G[g_bsfc]);
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H)) return 1;
-    // lstm_cell_1 / W1_is / W1_ig: row blocks [0,4H), [4H,5H), [5H,6H) of dpre1^T against [h2_prev | vbar | x]
-    {
-        float* Gw[3] = {G[g_Wih1], G[g_Wis], G[g_Wig]};
-        const int r0[3] = {0, 4 * H, 5 * H}, nr[3] = {4 * H, H, H};
-        for (int i = 0; i < 3; ++i) {
-            const float* dy = t.tY_dpre1 + (size_t)r0[i] * TBp;
-            if (d.h2_first_lstm && gemm_to1(h, t, s, nr[i], H, TBp, dy, TBp, t.tX_h2prev, TBp, Gw[i], in1)) return 1;
-            if (gemm_to1(h, t, s, nr[i], D, Bp, t.tY_dpre1sum + (size_t)r0[i] * Bp, Bp, t.tX_vbar, Bp, Gw[i] + voff, in1)) return 1;
-            if (gemm_to1(h, t, s, nr[i], E, TBp, dy, TBp, t.tX_x, TBp, Gw[i] + xoff, in1)) return 1;
-        }
-        if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H)) return 1;
-        if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H)) return 1;
-        colsum(t, s, t.dpre1, (long long)6 * H, TB, 4 * H, G[g_bih1]);
-        HIPCHK(hipMemcpyAsync(G[g_bhh1], G[g_bih1], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
-        colsum(t, s, t.dpre1 + 4 * H, (long long)6 * H, TB, H, G[g_bis]);
-        HIPCHK(hipMemcpyAsync(G[g_bhs], G[g_bis], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-        colsum(t, s, t.dpre1 + 5 * H, (long long)6 * H, TB, H, G[g_big]);
-        HIPCHK(hipMemcpyAsync(G[g_bhg], G[g_big], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
     // att_va: dP^T (A, NV) x regions^T (D, NV) over the non-padding rows
     if (NV > 0) {
         if (gemm_to1(h, t, s, A, D, NVp, t.tY_dP, NVp, t.tX_reg, NVp, G[g_Wva], D)) return 1;
     } else {
         HIPCHK(hipMemsetAsync(G[g_Wva], 0, (size_t)A * D * sizeof(float), s));
     }
-    // the three score vectors
+    HIPCHK(hipEventRecord(t.bucket_ev[3], s));
+    // ---- bucket 4 (the tail, 3.5 M floats): W1_hg, att_ha, att_sa, att_ga and the three score vectors
+    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H)) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H)) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H)) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H)) return 1;
     colsum(t, s, t.dwa_rows, (long long)A, TB, A, G[g_wa]);
     colsum(t, s, t.dws_rows, (long long)A, TB, A, G[g_ws]);
     colsum(t, s, t.dwg_rows, (long long)A, TB, A, G[g_wg]);
-    // embedding: dx = dpre1 . [W_ih1 ; W_is ; W_ig][:, x columns], scattered onto the rows that were looked up
-    {
-        SegSpec sg[3] = {{t.dpre1, 6 * H, t.wT_ih1 + (size_t)xoff * 4 * H, 4 * H, 4 * H},
-                         {t.dpre1 + 4 * H, 6 * H, t.wT_is + (size_t)xoff * H, H, H},
-                         {t.dpre1 + 5 * H, 6 * H, t.wT_ig + (size_t)xoff * H, H, H}};
-        if (gemm_to(h, t, s, TB, E, sg, 3, t.dx_all, E)) return 1;
-        HIPCHK(hipMemsetAsync(G[g_embed], 0, (size_t)V * E * sizeof(float), s));
-        hipLaunchKernelGGL(k_scatter_add_rows, dim3(cdiv((long long)TB * E, 256)), dim3(256), 0, s, t.dx_all, t.word32, TB, E, G[g_embed]);
-    }
+    HIPCHK(hipEventRecord(t.bucket_ev[4], s));
+    t.buckets_recorded = true;
     LAUNCHCHK();
+    return 0;
+}
+
+// Completion order of the 28 gradients inside vsr_train_backward: bucket_of[i] (field order of vsr_weights) in
+// [0, VSR_GRAD_BUCKETS); bucket b is complete when its event has fired.  Static (does not depend on the shapes).
+extern "C" int vsr_train_bucket_map(int32_t* bucket_of, int32_t* n_buckets) {
+    if (!bucket_of || !n_buckets) return fail("vsr_train_bucket_map: null argument");
+    enum { g_embed, g_Wis, g_bis, g_Whs, g_bhs, g_Wva, g_Wha, g_wa, g_Wsa, g_ws, g_Wih1, g_Whh1, g_bih1, g_bhh1, g_Wih2, g_Whh2, g_bih2,
+           g_bhh2, g_Wout, g_bout, g_Wsfc, g_bsfc, g_Wig, g_big, g_Whg, g_bhg, g_Wga, g_wg };
+    const int b0[] = {g_Wih1, g_Wis, g_Wig}, b1[] = {g_Wih2, g_Whh2, g_bih2, g_bhh2}, b2[] = {g_Wout, g_bout, g_embed},
+              b3[] = {g_Whh1, g_Whs, g_bih1, g_bhh1, g_bis, g_bhs, g_big, g_bhg, g_Wsfc, g_bsfc, g_Wva},
+              b4[] = {g_Whg, g_Wha, g_Wsa, g_Wga, g_wa, g_ws, g_wg};
+    for (int i = 0; i < 28; ++i) bucket_of[i] = -1;
+    for (int i : b0) bucket_of[i] = 0;
+    for (int i : b1) bucket_of[i] = 1;
+    for (int i : b2) bucket_of[i] = 2;
+    for (int i : b3) bucket_of[i] = 3;
+    for (int i : b4) bucket_of[i] = 4;
+    for (int i = 0; i < 28; ++i)
+        if (bucket_of[i] < 0) return fail("vsr_train_bucket_map: gradient %d has no bucket", i);
+    *n_buckets = VSR_GRAD_BUCKETS;
+    return 0;
+}
+
+// Make `stream` wait (on the device; the host does not block) until bucket `bucket` of the last vsr_train_backward is complete.
+extern "C" int vsr_train_wait_bucket(vsr_handle* h, int32_t bucket, void* stream) {
+    if (!h || !h->tc) return fail("vsr_train_wait_bucket: null handle");
+    TrainCtx& t = *h->tc;
+    if (bucket < 0 || bucket >= VSR_GRAD_BUCKETS) return fail("vsr_train_wait_bucket: bucket %d not in [0, %d)", bucket, VSR_GRAD_BUCKETS);
+    if (!t.buckets_recorded) return fail("vsr_train_wait_bucket: no backward pass has run on this handle");
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, t.bucket_ev[bucket], 0));
     return 0;
 }
 

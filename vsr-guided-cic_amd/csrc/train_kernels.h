@@ -83,12 +83,44 @@ __global__ void k_gather_rows(const float* __restrict__ table, const int* __rest
     const int r = (int)(i / E), e = (int)(i % E);
     out[i] = table[(long long)idx[r] * E + e];
 }
-// dEmbed[idx[r]] += dx[r]   (float atomics: rows may repeat inside a batch)
-__global__ void k_scatter_add_rows(const float* __restrict__ dx, const int* __restrict__ idx, int rows, int E, float* __restrict__ table_grad) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)rows * E) return;
-    const int r = (int)(i / E), e = (int)(i % E);
-    atomicAdd(table_grad + (long long)idx[r] * E + e, dx[i]);
+// dEmbed[w] = sum of dx[r] over the rows r with idx[r] == w, IN ASCENDING r: a deterministic segmented sum (float atomics
+// gave run-to-run different bits whenever a word repeats inside a batch).  One workgroup per row r; it only works when r is
+// the FIRST occurrence of its word (every wave scans the id list 64 entries at a time and leaves as soon as it sees an earlier
+// one), then adds the later occurrences in order.  The table gradient is zero-filled beforehand for the untouched rows.
+__global__ __launch_bounds__(256) void k_embed_grad_rows(const float* __restrict__ dx, const int* __restrict__ idx, int rows, int E,
+                                                         float* __restrict__ table_grad) {
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int w = idx[r];
+    constexpr int CMAX = 8;                         // columns per thread: E <= 2048 in one pass, more in further passes
+    for (int e0 = 0; e0 < E; e0 += 256 * CMAX) {
+        float acc[CMAX];
+#pragma unroll
+        for (int q = 0; q < CMAX; ++q) acc[q] = 0.f;
+        for (int c0 = 0; c0 < rows; c0 += 64) {
+            const int j = c0 + lane;
+            const bool hit = j < rows && idx[j] == w;
+            unsigned long long m = __ballot(hit);
+            if (c0 < r) {                            // an earlier row owns this word (wave-uniform exit)
+                const unsigned long long before = (r - c0 >= 64) ? ~0ull : ((1ull << (r - c0)) - 1ull);
+                if (m & before) return;
+            }
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float* src = dx + (long long)(c0 + b) * E + e0;
+#pragma unroll
+                for (int q = 0; q < CMAX; ++q) {
+                    const int e = tid + 256 * q;
+                    if (e0 + e < E) acc[q] += src[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < CMAX; ++q) {
+            const int e = e0 + tid + 256 * q;
+            if (e < E) table_grad[(long long)w * E + e] = acc[q];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- forward saves

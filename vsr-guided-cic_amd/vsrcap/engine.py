@@ -63,6 +63,7 @@ class Engine:
         self._prep_key = None
         self._keep = None
         self._verb_dev = None
+        self.grad_sink = None       # list of 28 tensors (WEIGHT_FIELDS order): backward writes there and autograd gets no tensors
 
     def __del__(self):
         try:
@@ -253,9 +254,11 @@ class Engine:
         return int(self.lib.vsr_train_generation(self.h))
 
     @_on_device
-    def train_backward(self, device, grad_out, grad_gate, shapes, generation=None):
+    def train_backward(self, device, grad_out, grad_gate, shapes, generation=None, into=None):
         """shapes: list of the 28 parameter shapes in WEIGHT_FIELDS order -> list of gradient tensors.
-        generation: train_generation() recorded right after the forward this backward belongs to."""
+        generation: train_generation() recorded right after the forward this backward belongs to.
+        into: optional list of 28 caller tensors (e.g. views of ONE flat buffer, parallel.FlatGrads) the library writes
+        the gradients to instead of fresh allocations."""
         if generation is not None and generation != self.train_generation():
             raise RuntimeError(
                 "backward of a forward pass whose saved activations are gone: the handle keeps ONE training forward at a "
@@ -264,10 +267,28 @@ class Engine:
                 "over separate forward+backward pairs instead of loss = l1 + l2.")
         grad_out = _f32(grad_out, "grad of word log-probs")
         grad_gate = _f32(grad_gate, "grad of gate log-probs")
-        grads = [torch.empty(s, dtype=torch.float32, device=device) for s in shapes]
+        if into is not None:
+            grads = list(into)
+            for g, sh in zip(grads, shapes):
+                if tuple(g.shape) != tuple(sh) or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous():
+                    raise RuntimeError("gradient sink tensor does not match its parameter (%s vs %s)" % (tuple(g.shape), tuple(sh)))
+        else:
+            grads = [torch.empty(s, dtype=torch.float32, device=device) for s in shapes]
         g = _lib.VsrWeights(*[t.data_ptr() for t in grads])
         _lib.check(self.lib.vsr_train_backward(self.h, _ptr(grad_out), _ptr(grad_gate), C.byref(g), self._stream(device)))
         return grads
+
+    def bucket_map(self):
+        """(bucket_of[28] in WEIGHT_FIELDS order, n_buckets): completion order of the gradients in vsr_train_backward"""
+        arr = (C.c_int32 * 28)()
+        n = C.c_int32(0)
+        _lib.check(self.lib.vsr_train_bucket_map(arr, C.byref(n)))
+        return list(arr), n.value
+
+    @_on_device
+    def wait_bucket(self, bucket, stream):
+        """make torch stream `stream` wait on the device until gradient bucket `bucket` of the last backward is complete"""
+        _lib.check(self.lib.vsr_train_wait_bucket(self.h, int(bucket), C.c_void_p(stream.cuda_stream)))
 
     @_on_device
     def debug_buffer(self, name, shape, device):

@@ -4,10 +4,16 @@
 
 Decode shards IMAGES and needs no data-path collective (beams never cross images, CaptioningModel.py:107-109):
     lo, hi = shard_bounds(n_images, world, rank); ids = model.beam_search(...shard...); all = gather_ids(ids, n_images)
-Training is data parallel: gradients are summed over ranks in flat buckets; both XE losses are normalised by GLOBAL
-counts (coco_scripts/train.py:108-109: the word loss averages over B*(T-1) targets, the gate loss over the targets
-that are not ignore_index = -1), so uneven shards (100 images on 8 GPUs = 13,13,13,13,12,12,12,12) and data-dependent
-ignore counts give exactly the single-process loss and update.
+Training is data parallel.  Both XE losses are normalised by GLOBAL counts (coco_scripts/train.py:108-109: the word loss
+averages over B*(T-1) targets, the gate loss over the targets that are not ignore_index = -1), so uneven shards (100 images
+on 8 GPUs = 13,13,13,13,12,12,12,12) and data-dependent ignore counts give exactly the single-process loss and update.
+
+Gradient exchange: the 28 gradients live in ONE flat fp32 buffer (FlatGrads) laid out in the order in which
+vsr_train_backward completes them (vsr_train_bucket_map: 5 buckets, largest first, 97 / 65 / 80 / 30 / 14 MB at the full
+model); the parameters' .grad are views of it - no torch.cat, no copy back.  The library records a HIP event after each
+bucket; the all-reduce of bucket b is launched on a side stream behind that event, so it runs under the weight-gradient
+GEMMs of buckets b+1.. (xGMI rings are per-link bound: few, large, contiguous collectives).  The optimizer step waits for
+the last bucket only.
 """
 import torch
 import torch.distributed as dist
@@ -24,7 +30,6 @@ def shard_bounds(n, world, rank):
 def gather_ids(local, n_total, group=None):
     """all-gather (b_local, ...) integer tensors of uneven first dimension into (n_total, ...)."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     cap = max(shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world))
     pad = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
@@ -37,9 +42,44 @@ def gather_ids(local, n_total, group=None):
     return torch.cat(out, 0)
 
 
+class FlatGrads:
+    """One flat fp32 gradient buffer; .views[i] is the gradient of params[i] and stays its .grad for the whole run.
+    order / bucket_of: position of every parameter in the buffer (bucket-major) - contiguous ranges per bucket."""
+
+    def __init__(self, params, bucket_of=None):
+        self.params = list(params)
+        n = len(self.params)
+        bucket_of = list(bucket_of) if bucket_of is not None else [0] * n
+        order = sorted(range(n), key=lambda i: (bucket_of[i], i))
+        total = sum(p.numel() for p in self.params)
+        p0 = self.params[0]
+        self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        self.views = [None] * n
+        self.ranges = []                     # per bucket: (lo, hi) in the flat buffer
+        off, cur, lo = 0, None, 0
+        for i in order:
+            if bucket_of[i] != cur:
+                if cur is not None:
+                    self.ranges.append((lo, off))
+                cur, lo = bucket_of[i], off
+            k = self.params[i].numel()
+            self.views[i] = self.flat[off:off + k].view_as(self.params[i])
+            off += k
+        self.ranges.append((lo, off))
+
+    def attach(self):
+        """(re)install the views as .grad (optimizer.zero_grad(set_to_none=True) would have dropped them)"""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def bucket(self, b):
+        lo, hi = self.ranges[b]
+        return self.flat[lo:hi]
+
+
 def allreduce_gradients(params, bucket_bytes=64 << 20, group=None):
-    """SUM-all-reduce .grad of params in flat buckets (few large collectives: xGMI rings are per-link bound, so
-    bucket size matters more than count).  All buckets are launched asynchronously, then unpacked in order."""
+    """Generic helper (any model, any backend): SUM-all-reduce .grad of params in flat buckets.  DataParallelStep does
+    not use it (its gradients already live in one flat buffer)."""
     params = [p for p in params if p.grad is not None]
     buckets, cur, cur_bytes = [], [], 0
     for p in params:
@@ -67,24 +107,76 @@ def allreduce_gradients(params, bucket_bytes=64 << 20, group=None):
 class DataParallelStep:
     """One optimisation step of the XE (train.py:99-113) or SCST (train.py:151-178) phase on this rank's shard.
 
-    forward_fn(det, captions, ctrl_seq) -> (logp_words (b,T,V), logp_gates (b,T,2)) with a graph; on the GPU it is
-    `lambda d, c, s: model((d,), (c, s))`.  sample_fn(det, ctrl) -> ((words, gates), (lp_w, lp_g))."""
+    model_or_params: the HIP ControllableCaptioningModel (gradients then go straight from vsr_train_backward into the flat
+    buffer and are exchanged bucket by bucket behind the library's events), or a plain parameter list (CPU tests with the
+    oracle: autograd accumulates into the flat views in place, buckets are exchanged after backward).
+    forward_fn(det, captions, ctrl_seq) -> (logp_words (b,T,V), logp_gates (b,T,2)) with a graph.
+    sample_fn(det, ctrl) -> ((words, gates), (lp_w, lp_g)).
+    all_reduce_fn(tensor) -> None: override of the SUM collective (tests: gloo through host memory)."""
 
-    def __init__(self, params, optimizer, forward_fn=None, sample_fn=None, group=None, bucket_bytes=64 << 20):
-        self.params = list(params)
+    def __init__(self, model_or_params, optimizer, forward_fn=None, sample_fn=None, group=None, all_reduce_fn=None):
+        self.model = model_or_params if hasattr(model_or_params, "_engine") else None
         self.opt = optimizer
         self.forward_fn = forward_fn
         self.sample_fn = sample_fn
         self.group = group
-        self.bucket_bytes = bucket_bytes
+        self.all_reduce_fn = all_reduce_fn
+        if self.model is not None:
+            from . import _lib
+            sd = dict(self.model.named_parameters())
+            self.params = [sd[k] for _, k in _lib.WEIGHT_FIELDS]
+            dev = self.params[0].device
+            self.eng = self.model._engine(dev)
+            bucket_of, self.n_buckets = self.eng.bucket_map()
+            self.grads = FlatGrads(self.params, bucket_of)
+            self.eng.grad_sink = self.grads.views
+            self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        else:
+            self.params = list(model_or_params)
+            self.eng = None
+            self.grads = FlatGrads(self.params)
+            self.n_buckets = 1
+            self.comm_stream = None
 
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def _sum(self, t):
         if self._world() > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self.all_reduce_fn is not None:
+                self.all_reduce_fn(t)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def _backward_and_exchange(self, loss):
+        g = self.grads
+        if self.eng is None:
+            g.flat.zero_()                   # autograd ACCUMULATES into existing .grad tensors: start from zero, in place
+        g.attach()
+        loss.backward()
+        if self._world() == 1:
+            return
+        if self.eng is None or self.comm_stream is None:
+            for b in range(len(g.ranges)):
+                self._sum(g.bucket(b))
+            return
+        # HIP path: the whole backward is enqueued (the host is ahead of the GPU); bucket b's collective goes to the side
+        # stream behind the library's event for bucket b and overlaps the GEMMs of the later buckets
+        main = torch.cuda.current_stream(g.flat.device)
+        works = []
+        for b in range(self.n_buckets):
+            self.eng.wait_bucket(b, self.comm_stream)
+            with torch.cuda.stream(self.comm_stream):
+                buf = g.bucket(b)
+                if self.all_reduce_fn is not None:
+                    self.all_reduce_fn(buf)
+                else:
+                    works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        with torch.cuda.stream(self.comm_stream):
+            for w in works:
+                w.wait()                     # RCCL's internal stream -> side stream
+        main.wait_stream(self.comm_stream)   # the optimizer step (main stream) needs every bucket
 
     def xe_step(self, det, captions, ctrl_seq, gate_gts):
         out, gate = self.forward_fn(det, captions, ctrl_seq)
@@ -92,32 +184,27 @@ class DataParallelStep:
         tgt_w = captions[:, 1:].reshape(-1)
         tgt_g = gate_gts.reshape(-1).long()
         # global denominators (no gradient flows through them)
-        counts = torch.tensor([float(tgt_w.numel()), float((tgt_g != -1).sum())], dtype=torch.float64, device=out.device)
+        counts = torch.tensor([float(tgt_w.numel()), 0.0], dtype=torch.float64, device=out.device)
+        counts[1] = (tgt_g != -1).sum()
         self._sum(counts)
         nll_w = F.nll_loss(out[:, :-1].reshape(-1, V), tgt_w, reduction="sum")
         nll_g = F.nll_loss(gate.reshape(-1, 2), tgt_g, ignore_index=-1, reduction="sum")
         loss_cap = nll_w / counts[0].to(nll_w.dtype)
         loss_gate = nll_g / counts[1].to(nll_g.dtype)
         loss = loss_cap + 4 * loss_gate                      # this rank's share of the global loss
-        self.opt.zero_grad()
-        loss.backward()
-        if self._world() > 1:
-            allreduce_gradients(self.params, self.bucket_bytes, self.group)
+        self._backward_and_exchange(loss)
         self.opt.step()
         stats = torch.stack([loss.detach(), loss_cap.detach(), loss_gate.detach()]).double()
         return self._sum(stats)                              # global loss, loss_cap, loss_gate
 
     def scst_step(self, det, ctrl, reward_fn):
-        """reward_fn(words (b,T)) -> (reward (b,), baseline (b,)) tensors: the CIDEr side is the caller's (out of scope)."""
+        """reward_fn(words (b,T)) -> (reward (b,), baseline (b,)) tensors (vsrcap.reward.CiderD on the device, or the caller's)."""
         (words, gates), (lp_w, lp_g) = self.sample_fn(det, ctrl)
         reward, baseline = reward_fn(words)
         n = torch.tensor([float(words.shape[0])], dtype=torch.float64, device=lp_w.device)
         self._sum(n)
         per = -(lp_w.mean(-1) + lp_g.mean(-1)) * (reward - baseline).to(lp_w.dtype)
         loss = per.sum() / n[0].to(per.dtype)
-        self.opt.zero_grad()
-        loss.backward()
-        if self._world() > 1:
-            allreduce_gradients(self.params, self.bucket_bytes, self.group)
+        self._backward_and_exchange(loss)
         self.opt.step()
         return self._sum(loss.detach().double().reshape(1))[0]

@@ -31,7 +31,12 @@ class _DecoderFn(torch.autograd.Function):
             g_out = torch.zeros_like(out)
         if g_gate is None:
             g_gate = torch.zeros_like(gate)
-        grads = ctx.eng.train_backward(ctx.device, g_out.contiguous(), g_gate.contiguous(), ctx.shapes, ctx.generation)
+        sink = ctx.eng.grad_sink
+        grads = ctx.eng.train_backward(ctx.device, g_out.contiguous(), g_gate.contiguous(), ctx.shapes, ctx.generation, into=sink)
+        if sink is not None:
+            # training-loop mode (parallel.FlatGrads): the gradients went straight into the caller's flat buffer, whose views
+            # ARE the parameters' .grad - nothing for autograd to accumulate (and no 285 MB of fresh tensors per step)
+            return (None,) * (5 + len(grads))
         return (None, None, None, None, None) + tuple(grads)
 
 
