@@ -338,3 +338,31 @@ def test_prepare_cache_invalidation():
         m.invalidate_cache()
         b = m.test(d, c)
     assert torch.equal(b[0], want[0]) and not torch.equal(a[0], b[0])
+
+
+# ------------------------------------------------------------------ every GEMM kernel variant keeps token parity
+@pytest.mark.parametrize("env", [dict(VSR_GEMM_TILE="64"), dict(VSR_GEMM_TILE="12864"), dict(VSR_GEMM_TILE="128"),
+                                 dict(VSR_GEMM_R16_MAX="0"), dict(VSR_GEMM_R16_MAX="256"), dict(VSR_GEMM_R16_MAX="512"),
+                                 dict(VSR_GEMM_SLOTS="384", VSR_GEMM_MIN_ITERS="4")])
+def test_gemm_kernel_variants_keep_token_parity(env, monkeypatch):
+    """The tile / kernel overrides read by vsr_create (64x64, 128x64, 128x128 tiles of the 32x32x2 kernel; the rows-16
+    16x16x4 kernel up to 0 / 256 / 512 rows; other stream-K grids) change the summation order, never the tokens: greedy on
+    40 rows and beam-5 on 24 rows of the 256-sample reference fixture, plus the shard-sized batch of 13."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    meta, g = load_golden("g2_greedy")
+    _, gb = load_golden("g3_beam")
+    m, _ = _model(meta)                                  # a fresh model -> a fresh handle that reads the environment
+    det, ctrl = helpers.decode_inputs(meta["cfg"], meta["seed"], n=40)
+    det, ctrl = det.to(DEV), ctrl.to(DEV)
+    with torch.no_grad():
+        w, gate = m.test(det, ctrl)
+        w13, g13 = m.test(det[:13].contiguous(), ctrl[:13].contiguous())
+        (bw, bg), _ = m.beam_search((det[:24].contiguous(), ctrl[:24].contiguous()), meta["eos"], 5, 1)
+    np.testing.assert_array_equal(w.cpu().numpy(), g["words"][:40].astype(np.int64))
+    np.testing.assert_array_equal(gate.cpu().numpy(), g["gates"][:40].astype(np.int64))
+    np.testing.assert_array_equal(w13.cpu().numpy(), g["words"][:13].astype(np.int64))
+    np.testing.assert_array_equal(g13.cpu().numpy(), g["gates"][:13].astype(np.int64))
+    solid = gb["agree64"][:24].astype(bool)
+    same = (bw.cpu().numpy() == gb["words"][:24]).all(1) & (bg.cpu().numpy() == gb["gates"][:24]).all(1)
+    assert same[solid].all()

@@ -353,38 +353,47 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant: the same stream-K decomposition and epilogue, but tiles go HBM/L2 -> LDS directly
-// (global_load_lds_dwordx4, no VGPR staging, no ds_write) into a ring of THREE stages, so the loads of tile i+2 are in
-// flight while tile i is being multiplied (prefetch distance 2 at 2 workgroups per CU: 3 x 24 KB for 128x64 tiles).
-//   * LDS rows are unpadded (32 floats = 8 chunks of 16 B, the DMA writes 1 KB per wave instruction linearly);
-//     bank conflicts are avoided by an XOR swizzle applied to the SOURCE chunk and to the read address:
-//     position p of row r holds chunk p ^ ((r >> 1) & 7)  (conflict-free for the ds_read_b128 lane groups).
-//   * K tails and nothing else read a 16-byte block of zeros instead of the matrix (per-lane source address).
-//   * one raw s_barrier per k-step, counted s_waitcnt vmcnt(N) (never 0 inside the loop except after an epilogue).
-__device__ float g_gemm_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+// ROWS-16 variant for short problems (M <= 128 per m-tile: greedy decoding, sampling, the per-step GEMMs of the
+// training pass at batch 100, a data-parallel shard of 13 images).
+//
+// The 32x32 MFMA tile pads M = 100 to 128 rows (28 % of the matrix work on zeros) and a 64x64 workgroup tile loads one
+// byte per 16 flop - and the k loop of these kernels is paced by the CU's vector-memory issue path, not by the matrix
+// pipe.  Here the matrix instruction is v_mfma_f32_16x16x4_f32 (same rate as 32x32x2, exact fp32),
+// rows come in units of 16 (100 -> 112: 11 % padding), and ONE workgroup holds every row of the m-tile against
+// BN = 64 TN weight rows: a 112 x 128 x 32 step loads 30 KB for 917 kflop (30 flop / byte, the 128x128 figure).
+//   workgroup = 8 waves: 4 side by side along n (wave & 3), times 2 halves of every 32-wide k-tile (wave >> 2): the K
+//   split stays INSIDE the workgroup (the two halves are added through LDS once per tile piece, in a fixed order), so a
+//   short problem (47 .. 125 n-tiles) still fills 256 CUs with at most 8 stream-K pieces per tile, every SIMD hosts two
+//   waves of one workgroup (one multiplies while the other waits on memory), and a wave issues 4 loads per k-step
+//   wave tile = (16 TM) x (16 TN); accumulators TM x TN x 4 registers
+//   lane (r = lane & 15, q = lane >> 4) owns matrix row r of every 16-row tile and the k's {4q..4q+3} + 16 (wave >> 2) of
+//   the k-tile: ONE ds_read_b128 feeds four MFMAs (A and B use the same k permutation, the sum is unchanged)
+//   LDS rows are unpadded (32 floats = 8 chunks of 16 B); chunk c of row R sits at position c ^ ((R >> 1) & 7): the
+//   b128 lane groups of that read pattern hit 64 distinct banks, and the ds_write_b128 of a row covers all 32 banks
+//   (a padded row stride cannot be conflict free for this pattern: the groups mix k-chunks q and q + 1).
+//   The global loads of the next k-tile are issued BETWEEN the MFMA groups (two loads, 14 MFMAs, ...): issued in one
+//   burst in front of them, a wave spends ~2 300 cycles queueing on the CU's address path before its first MFMA
+//   (measured: 6 000 cycles per k-step against 3 584 of MFMA with one wave per SIMD).
+// Stream-K decomposition, slab outputs, cursor and epilogue staging are those of gemm_nt_f32_kernel.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// One LDS-DMA request: every lane sends its 16 bytes at gsrc to LDS byte address lds_dst + 16 * lane.  Written in
-// asm on purpose: hipcc puts s_waitcnt vmcnt(0) in front of the next ds_read whenever it has SEEN a DMA in flight
-// (guide, "Three .s-level traps"), which would serialise the ring; the waits are counted by hand in the k loop.
-__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+constexpr int r16_band_tiles(int TM, int BN) {          // 16-row tiles per epilogue pass: the staging rows must fit one k buffer
+    int t = TM;
+    while (t > 1 && 16 * t * BN > (16 * TM + BN) * GEMM_BK) --t;
+    return t;
 }
 
-template <int TM, int TN, int WM = 2, int WN = 2>
-__global__ __launch_bounds__(64 * WM * WN)
-__attribute__((amdgpu_waves_per_eu(2, 2)))
-void gemm_nt_f32_dma_kernel(const GemmArgs args) {
-    constexpr int NT = 64 * WM * WN;
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int LR = NT / 8;
-    constexpr int LA = BM / LR, LB = BN / LR;
-    constexpr int STAGE = (BM + BN) * GEMM_BK;            // floats per stage (unpadded rows)
-    constexpr int NL = LA + LB;                           // DMA instructions per thread per tile
-    static_assert(BM % 64 == 0 && BM % LR == 0 && BN % LR == 0, "tile shape");
-    static_assert(64 * BN <= STAGE, "epilogue staging must fit one stage");
-    __shared__ __attribute__((aligned(1024))) float smem[3 * STAGE];
+template <int TM, int TN>
+__global__ __launch_bounds__(512)
+void gemm_nt_f32_r16_kernel(const GemmArgs args) {
+    constexpr int NT = 512;
+    constexpr int BM = 16 * TM, BN = 64 * TN;
+    constexpr int LA = (BM + 63) / 64, LB = BN / 64;     // float4 loads per thread per k-tile (64 rows per pass)
+    constexpr int A_TAIL = BM - 64 * (LA - 1);           // rows covered by the last A pass (64 = full)
+    constexpr int BUF = (BM + BN) * GEMM_BK;             // floats per k buffer
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+    auto sA = [&](int buf) { return smem + buf * BUF; };
+    auto sB = [&](int buf) { return smem + buf * BUF + BM * GEMM_BK; };
 
     const int G = args.G;
     const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
@@ -395,35 +404,38 @@ void gemm_nt_f32_dma_kernel(const GemmArgs args) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r = lane & 31, hh = lane >> 5;
-    const int lrow = tid >> 3;
-    const int lc4 = 4 * ((tid & 7) ^ ((lrow >> 1) & 7));  // swizzled SOURCE chunk of this lane's LDS position
-    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(wave);
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) void*)smem);
+    const int wn = wave & 3, wk = wave >> 2;              // n position, k half
+    const int r = lane & 15, q = lane >> 4;
+    const int lrow = tid >> 3;                            // 0..63
+    const int chunk = tid & 7;
+    const int lc4 = chunk * 4;                            // float offset inside the k-tile (global side)
+    const int wpos = 4 * (chunk ^ ((lrow >> 1) & 7));     // swizzled chunk position (LDS side); rows lrow + 64 i share it
+    const bool a_last_ok = lrow < A_TAIL;
 
-    // ---- load cursor (runs two iterations ahead)
+    // ------------------------------------------------------------------ load cursor (runs one iteration ahead)
+    float4 ra[LA], rb[LB];
     const float* pa[LA];
     const float* pb[LB];
-    int l_prob = 0, l_tile = 0, l_tile_left = 0, l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;
-    auto open_segment = [&](int sg, int first_tile) __attribute__((always_inline)) {
+    int l_prob = 0, l_tile = 0, l_tile_left = 0;
+    int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;
+    auto open_segment = [&](int s, int first_tile) __attribute__((always_inline)) {
         const GemmProb& P = args.p[l_prob];
-        const GemmSeg& S = P.seg[sg];
+        const GemmSeg& S = P.seg[s];
         const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
-        l_seg = sg;
+        l_seg = s;
         l_K = S.K;
         l_k = first_tile * GEMM_BK;
         l_seg_left = (S.K + GEMM_BK - 1) / GEMM_BK - first_tile;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            int m = m0 + lrow + LR * i;
+            int m = m0 + lrow + 64 * i;
             m = m < P.M ? m : P.M - 1;
             const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
             pa[i] = S.A + row * S.lda + lc4;
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            int n = n0 + lrow + LR * i;
+            int n = n0 + lrow + 64 * i;
             n = n < P.N ? n : P.N - 1;
             pb[i] = S.W + (long long)n * S.ldw + lc4;
         }
@@ -433,30 +445,42 @@ void gemm_nt_f32_dma_kernel(const GemmArgs args) {
         l_tile = tile;
         const GemmProb& P = args.p[prob];
         l_tile_left = P.ktiles - kt;
-        int sg = 0;
-        while (sg < P.nseg - 1 && kt >= (P.seg[sg].K + GEMM_BK - 1) / GEMM_BK) { kt -= (P.seg[sg].K + GEMM_BK - 1) / GEMM_BK; ++sg; }
-        open_segment(sg, kt);
+        int s = 0;
+        while (s < P.nseg - 1 && kt >= (P.seg[s].K + GEMM_BK - 1) / GEMM_BK) { kt -= (P.seg[s].K + GEMM_BK - 1) / GEMM_BK; ++s; }
+        open_segment(s, kt);
     };
-    auto issue_next = [&](int stage) __attribute__((always_inline)) {     // DMA the cursor's tile into `stage`, advance
+    int l_ko = 0;                                          // k offset of the tile being loaded (0 in the K tail: a valid address)
+    auto advance = [&]() __attribute__((always_inline)) {  // move the cursor to the next k-tile (wave-uniform bookkeeping)
         if (l_tile_left == 0) {
             if (l_tile + 1 < args.p[l_prob].tiles_m * args.p[l_prob].tiles_n) open_tile(l_prob, l_tile + 1, 0);
             else open_tile(l_prob + 1, 0, 0);
         } else if (l_seg_left == 0) {
             open_segment(l_seg + 1, 0);
         }
-        const bool kin = l_k + lc4 < l_K;
-        // wave-uniform LDS byte address of this wave's first 8-row group in the stage
-        const unsigned base = lds0 + (unsigned)__builtin_amdgcn_readfirstlane(stage) * (STAGE * 4) + wave_u * (8 * GEMM_BK * 4);
-#pragma unroll
-        for (int i = 0; i < LA; ++i) glds16(kin ? pa[i] + l_k : g_gemm_zero16, base + (LR * i) * (GEMM_BK * 4));
-#pragma unroll
-        for (int i = 0; i < LB; ++i) glds16(kin ? pb[i] + l_k : g_gemm_zero16, base + (BM + LR * i) * (GEMM_BK * 4));
+        l_ko = (l_k + lc4 < l_K) ? l_k : 0;
         l_k += GEMM_BK;
         --l_seg_left;
         --l_tile_left;
     };
+    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = *reinterpret_cast<const float4*>(pa[i] + l_ko); };
+    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = *reinterpret_cast<const float4*>(pb[i] + l_ko); };
+    auto store_tile = [&](int buf) __attribute__((always_inline)) {
+        if (!(l_k - GEMM_BK + lc4 < l_K)) {                // K tail of the tile in flight (l_k has advanced by BK): zeros
+#pragma unroll
+            for (int i = 0; i < LA; ++i) ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < LB; ++i) rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            if (i + 1 < LA || a_last_ok)
+                *reinterpret_cast<float4*>(sA(buf) + (lrow + 64 * i) * GEMM_BK + wpos) = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            *reinterpret_cast<float4*>(sB(buf) + (lrow + 64 * i) * GEMM_BK + wpos) = rb[i];
+    };
 
-    // ---- compute-side bookkeeping (identical to the register-staged kernel)
+    // ------------------------------------------------------------------ compute-side tile bookkeeping
     int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0;
     bool c_last = false;
     auto decode = [&](int it) __attribute__((always_inline)) {
@@ -478,39 +502,51 @@ void gemm_nt_f32_dma_kernel(const GemmArgs args) {
         return kt;
     };
 
-    constexpr int ST_LD = (64 * (BN + 4) <= STAGE) ? BN + 4 : BN;
-    auto flush = [&](const f32x16 (&acc)[TM][TN], float* stage) __attribute__((always_inline)) {
+    // Epilogue: accumulator element e of tile (ti, tj) is C[16 ti + 4 q + e][16 TN wn + 16 tj + r].  TB 16-row tiles per
+    // pass go through the idle k buffer: the k-half-1 waves put their sums there, the k-half-0 waves add their own on top
+    // (half 0 + half 1, always in that order), then the rows leave as 16-byte stores (512-byte runs per row).
+    constexpr int TB = r16_band_tiles(TM, BN);
+    auto flush = [&](const f32x4 (&acc)[TM][TN], float* stage) __attribute__((always_inline)) {
         const GemmProb& P = args.p[c_prob];
         const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
         float* C = P.C + (long long)c_piece * P.slab_stride;
         const int extra = c_last ? args.nslab - 1 - c_piece : 0;
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
-        constexpr int TPR = BN / 4;
-        constexpr int RPP = NT / TPR;
+        constexpr int TPR = BN / 4;                        // threads per staged row
+        constexpr int RPP = NT / TPR;                      // rows per store pass
         const int c4 = (tid % TPR) * 4;
         const int n = n0 + c4;
-        __builtin_amdgcn_s_barrier();                      // everybody is done reading the stage that becomes the staging buffer
 #pragma unroll
-        for (int band = 0; band < BM / 64; ++band) {
+        for (int b0 = 0; b0 < TM; b0 += TB) {
+            if (wk == 1) {
 #pragma unroll
-            for (int ti = 0; ti < TM; ++ti) {
-                const int trow = wm * TM + ti;
-                if ((trow >> 1) == band) {
+                for (int ti = b0; ti < TM && ti < b0 + TB; ++ti)
 #pragma unroll
                     for (int tj = 0; tj < TN; ++tj)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            stage[((trow & 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e];
-                }
+                        for (int e = 0; e < 4; ++e)
+                            stage[((ti - b0) * 16 + 4 * q + e) * BN + wn * (16 * TN) + tj * 16 + r] = acc[ti][tj][e];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            __syncthreads();
+            if (wk == 0) {
 #pragma unroll
-            for (int i = 0; i < 64 / RPP; ++i) {
+                for (int ti = b0; ti < TM && ti < b0 + TB; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float* sp = stage + ((ti - b0) * 16 + 4 * q + e) * BN + wn * (16 * TN) + tj * 16 + r;
+                            *sp = acc[ti][tj][e] + *sp;
+                        }
+            }
+            __syncthreads();
+            constexpr int BAND = 16 * TB;
+#pragma unroll
+            for (int i = 0; i < (BAND + RPP - 1) / RPP; ++i) {
                 const int sr = tid / TPR + RPP * i;
-                const int m = m0 + band * 64 + sr;
-                if (m < P.M && n < P.N) {
-                    const float4 v = *reinterpret_cast<const float4*>(stage + sr * ST_LD + c4);
+                const int m = m0 + 16 * b0 + sr;
+                if (sr < BAND && 16 * b0 + sr < BM && m < P.M && n < P.N) {
+                    const float4 v = *reinterpret_cast<const float4*>(stage + sr * BN + c4);
                     float* dst = C + (long long)m * P.ldc + n;
                     if (vec_ok && n + 3 < P.N) {
                         *reinterpret_cast<float4*>(dst) = v;
@@ -518,73 +554,111 @@ void gemm_nt_f32_dma_kernel(const GemmArgs args) {
                             *reinterpret_cast<float4*>(dst + (long long)x * P.slab_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
                     } else {
                         const float vv[4] = {v.x, v.y, v.z, v.w};
-                        for (int q = 0; q < 4; ++q)
-                            if (n + q < P.N) {
-                                dst[q] = vv[q];
-                                for (int x = 1; x <= extra; ++x) dst[(long long)x * P.slab_stride + q] = 0.f;
+                        for (int qq = 0; qq < 4; ++qq)
+                            if (n + qq < P.N) {
+                                dst[qq] = vv[qq];
+                                for (int x = 1; x <= extra; ++x) dst[(long long)x * P.slab_stride + qq] = 0.f;
                             }
                     }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            __syncthreads();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stores share the VM counter with the DMA: restart the count
     };
 
     {
         const int kt = decode(it0);
         open_tile(c_prob, c_tile, kt);
     }
-    int issued = it0;                                      // next iteration whose tile has not been requested yet
-    issue_next(0);
-    ++issued;
-    if (issued < it1) { issue_next(1); ++issued; }
-    int st = 0;                                            // stage of the tile being multiplied
+    advance();
+#pragma unroll
+    for (int i = 0; i < LA; ++i) load_a(i);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) load_b(i);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    const int ch = 4 * ((q + 4 * wk) ^ (r >> 1));          // this wave's k chunk, swizzled: ((16 t + r) >> 1) & 7 = r >> 1 for every tile t
     for (int it = it0; it < it1;) {
-        f32x16 acc[TM][TN];
+        f32x4 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
         const int n_it = c_left;
         for (int j_it = 0; j_it < n_it; ++j_it, ++it) {
-            // tile `it` has landed once at most the younger tile's NL requests are outstanding
-            if (issued > it + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                  // ... for every wave; and stage (st + 2) % 3 is free again
-            int st2 = st + 2;
-            st2 = st2 >= 3 ? st2 - 3 : st2;
-            if (issued < it1) { issue_next(st2); ++issued; }
-            const float* a_base = smem + st * STAGE + (wm * (32 * TM) + r) * GEMM_BK;
-            const float* b_base = smem + st * STAGE + BM * GEMM_BK + (wn * (32 * TN) + r) * GEMM_BK;
-            const int sw = (r >> 1) & 7;
+            const bool more = it + 1 < it1;
+            if (more) advance();
+            const float* a_base = sA(cur) + r * GEMM_BK + ch;
+            const float* b_base = sB(cur) + (wn * (16 * TN) + r) * GEMM_BK + ch;
+            float4 av[TM], bv[TN];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                float4 av[TM], bv[TN];
-                const int ch = 4 * (((2 * kk + hh) ^ sw));
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(a_base + i * 16 * GEMM_BK);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(a_base + i * 32 * GEMM_BK + ch);
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(b_base + j * 16 * GEMM_BK);
+            // Next tile's global loads, STAGGERED between the two waves of a SIMD (waves w and w + 4 = the two k halves): the
+            // k-half-0 wave issues its loads in front of its MFMAs, the k-half-1 wave behind its third MFMA group, so one of
+            // them multiplies while the other queues on the CU's address path (lock-stepped, both would queue, then both multiply).
+#ifndef R16_LOADPOS
+#define R16_LOADPOS 0
+#endif
+            auto loads = [&]() __attribute__((always_inline)) {
+                if (more && GEMM_ABLATE < 1) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(b_base + j * 32 * GEMM_BK + ch);
+                    for (int i = 0; i < LA; ++i) load_a(i);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < LB; ++i) load_b(i);
+                }
+            };
+            if (R16_LOADPOS == 0 || (R16_LOADPOS == 1 && wk == 0)) loads();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
-                    }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (R16_LOADPOS == 2 || (R16_LOADPOS == 1 && wk == 1)) loads();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+#ifndef R16_MIDREFILL
+#define R16_MIDREFILL 1
+#endif
+#if R16_MIDREFILL == 1
+            // refill of the OTHER k buffer (free since the barrier that ended the previous iteration) in the middle of the MFMA
+            // stream: its ds_writes and the wait for the loads overlap the partner wave's MFMAs; only the barrier is left at the end
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && GEMM_ABLATE < 2) store_tile(cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+#if R16_MIDREFILL == 2
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && GEMM_ABLATE < 2) store_tile(cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && GEMM_ABLATE < 2) {
+#if R16_MIDREFILL == 0
+                store_tile(cur ^ 1);
+#endif
+                __syncthreads();
+                cur ^= 1;
             }
-            st = st + 1 >= 3 ? 0 : st + 1;
         }
-        // the stage just multiplied from is (st + 2) % 3: the two others hold / receive the next tiles
-        int sfree = st + 2;
-        sfree = sfree >= 3 ? sfree - 3 : sfree;
-        flush(acc, smem + sfree * STAGE);
+        if (GEMM_ABLATE < 3) flush(acc, sA(cur ^ 1));
+        else asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][3]));
         if (it < it1) decode(it);
     }
 }

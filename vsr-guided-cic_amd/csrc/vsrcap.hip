@@ -90,8 +90,15 @@ struct vsr_handle {
     int gemm_slots = 1024;       // resident 64x64 GEMM workgroups to fill: 256 CUs x 4 (36.9 KB LDS each)
     int gemm_slots_small = 768;  // 64x64 tiles (M <= 192): 3 per CU measured best (greedy 473 k vs 461 k tokens/s at 4 per CU)
     int gemm_min_iters = 8;
+    int gemm_slots_r16 = 256;    // rows-16 kernel: ONE 8-wave workgroup per CU (two waves per SIMD)
+    // Problems with at most this many rows take the rows-16 kernel (VSR_GEMM_R16_MAX=0 disables it).  Measured end to end on
+    // one MI355X: at M = 100 it is level with the 64x64 kernel inside a GEMM (61.5 vs 60.6 TF/s) but its tiles are cut into
+    // 7-8 stream-K pieces instead of 4-6, and the consumers' extra slab reads cost more than its 11 %-instead-of-28 %
+    // padding saves (greedy 459 k vs 481 k tokens/s, XE step 6.8 k vs 7.4 k samples/s).  Below 64 rows (a data-parallel
+    // shard of 12-13 images, small eval batches) the 64-row tile is mostly padding and the rows-16 kernel wins
+    // (M = 13: 19.5 vs 13.2 TF/s over the four step GEMMs).
+    int gemm_r16_max = 48;
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
-    int gemm_dma = 0;            // VSR_GEMM_DMA=1: LDS-DMA 3-stage variant for the 128x64 tile (measured equal: DESIGN.md)
     int gemm_tile = 0;           // 0 = by M; VSR_GEMM_TILE=64 | 12864 | 128 forces 64x64 / 128x64 / 128x128
     Ctx c;
     // measurement
@@ -194,12 +201,20 @@ struct GemmBuilder {
         GemmSeg& s = p.seg[p.nseg++];
         s.A = A; s.lda = lda; s.a_idx = idx; s.W = W; s.ldw = ldw; s.K = K;
     }
-    int big = 0;       // 1: 128x128 workgroup tiles (2x2 MFMA tiles per wave), 0: 64x64
+    int big = 0;       // 2: 128x128 workgroup tiles, 1: 128x64, 0: 64x64 (32x32x2 MFMA); 16: rows-16 kernel (16x16x4 MFMA), r16_tm tiles
+    int r16_tm = 0;
     // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
     int finish(const vsr_handle* h) {
         int maxM = 0;
         for (int i = 0; i < a.nprob; ++i) maxM = std::max(maxM, a.p[i].M);
         big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM >= 1024 ? 2 : maxM > 192 ? 1 : 0);
+        if (h->gemm_tile == 0 && maxM <= h->gemm_r16_max) {
+            // short problems: every row of an m-tile in one workgroup, rows in units of 16 (M = 100 -> 112, not 128)
+            const int tiles = (maxM + 127) / 128;
+            r16_tm = (((maxM + tiles - 1) / tiles) + 15) / 16;
+            big = 16;
+            return gemm_plan(a, h->gemm_slots_r16, 4, 16 * r16_tm, 128);
+        }
         // resident workgroups per CU: 4 at 36.9 KB LDS (64x64), 2 at 55.3 KB (128x64) or 73.7 KB (128x128).
         // 128x128 for M >= 1024 (weight-gradient GEMMs: one tile per workgroup, 130 TF/s at long K);
         // 128x64 is the default for tall problems: as fast as 128x128 in the GEMM itself (91.8 vs 93.7 TF/s) but its
@@ -210,11 +225,21 @@ struct GemmBuilder {
 };
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
-    dim3 grid(((a.G + 7) / 8) * 8), block(256);
+    dim3 grid(((a.G + 7) / 8) * 8), block(big == 16 ? 512 : 256);
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
-    if (big == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), grid, block, 0, s, a);
-    else if (big == 1 && h->gemm_dma) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<2, 1>), grid, block, 0, s, a);
+    if (big == 16) {
+        switch (r16_tm) {
+            case 1: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<1, 2>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<2, 2>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<3, 2>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<4, 2>), grid, block, 0, s, a); break;
+            case 5: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<5, 2>), grid, block, 0, s, a); break;
+            case 6: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<6, 2>), grid, block, 0, s, a); break;
+            case 7: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<7, 2>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<8, 2>), grid, block, 0, s, a); break;
+        }
+    } else if (big == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 1) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 1>), grid, block, 0, s, a);
     if (prof) {
@@ -250,11 +275,13 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
         h->gemm_slots = prop.multiProcessorCount * 4;
         h->gemm_slots_small = prop.multiProcessorCount * 3;
+        h->gemm_slots_r16 = prop.multiProcessorCount;
     }
+    if (const char* e = getenv("VSR_GEMM_SLOTS_R16")) h->gemm_slots_r16 = std::max(1, atoi(e));
+    if (const char* e = getenv("VSR_GEMM_R16_MAX")) h->gemm_r16_max = atoi(e);
     if (const char* e = getenv("VSR_GEMM_SLOTS")) h->gemm_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_SMALL")) h->gemm_slots_small = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e);
-    if (const char* e = getenv("VSR_GEMM_DMA")) h->gemm_dma = atoi(e);
     if (const char* e = getenv("VSR_GEMM_MIN_ITERS")) h->gemm_min_iters = std::max(1, atoi(e));
     *out = h;
     return 0;
