@@ -204,12 +204,19 @@ def make_model(torch, synth, dev, train, dtype):
     return m, weights
 
 
-def roofline_block(dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic=None, traffic_source=None):
+def roofline_block(dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic=None, traffic_source=None, gemm_bytes=0.0):
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    if dtype == "bf16":
+        # bf16 operands take the matrix pipe out of the picture (16x the fp32 rate): the GEMMs are bound by the bytes they move
+        gbs = gemm_bytes / (gemm_ms * 1e-3) / 1e9 if gemm_ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": "gemm_nt_bf16w_kernel (v_mfma_f32_32x32x16_bf16; fp32 A converted on the way into LDS, bf16 W copies)",
+                "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": gemm_bytes / max(gemm_n, 1), "launches": gemm_seen, "launches_timed": gemm_n,
+                "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1), "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt,
+                "mfma_tflops_for_reference": achieved, "mfma_frac_of_dense_bf16_peak": achieved / PEAK_BF16_MFMA_TFLOPS}
+    peak = PEAK_F32_MFMA_TFLOPS
     r = {"bound": "mfma",
-         "kernel": "gemm_nt_f32_kernel / gemm_tn_f32_small_kernel (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)" if dtype == "f32"
-                   else "gemm_nt_bf16_kernel (v_mfma_f32_32x32x16_bf16)",
+         "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32; problems of <= 48 rows: gemm_nt_f32_r16_kernel, v_mfma_f32_16x16x4_f32)",
          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
          "launches": gemm_seen, "launches_timed": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
          "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt,
@@ -267,6 +274,7 @@ def decode_bench(args, D, torch, dist, synth):
     D.barrier()
     dt = time.perf_counter() - t0
     gemm_seen = eng.profile_seen()
+    gemm_bytes = eng.profile_bytes()
     gemm_ms, gemm_n, gemm_flops = eng.profile_end(dev)
     dt = D.max_time(dt)
     images = c["B"] if strong else world * c["B"]
@@ -285,7 +293,7 @@ def decode_bench(args, D, torch, dist, synth):
                    "rccl_world_size_observed": D.observed_world(),
                    "decode_cache": "prebuilt, weight-only (embedding rows through the x columns of the LSTM1 / gate input weights, "
                                    "240 MB, built once per weight version outside the timed call; all per-image hoisting is inside)"},
-        "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic, tsrc),
+        "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic, tsrc, gemm_bytes),
     }
     if indexed and rank == 0:
         dense = [(d, r.dense().contiguous()) for d, r in batches]
@@ -363,6 +371,7 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
     D.barrier()
     dt = time.perf_counter() - t0
     gemm_seen = eng.profile_seen()
+    gemm_bytes = eng.profile_bytes()
     gemm_ms, gemm_n, gemm_flops = eng.profile_end(dev)
     dt = D.max_time(dt)
     images = c["B"] if strong else world * c["B"]
@@ -378,7 +387,7 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
                    "batch_per_gpu": hi - lo, "seq_len": c["T"],
                    "parallelism": "dp%d, RCCL gradient all-reduce in buckets on a side stream, overlapped with the weight-gradient GEMMs" % world,
                    "rccl_world_size_observed": D.observed_world()},
-        "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt),
+        "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, gemm_bytes=gemm_bytes),
     }
     del m, opt, step, batches
     torch.cuda.empty_cache()

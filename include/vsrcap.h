@@ -100,6 +100,16 @@ int vsr_set_verb_table(vsr_handle* h, const int32_t* row_ptr, const int32_t* voc
 size_t vsr_decode_cache_floats(const vsr_handle* h);
 int vsr_build_decode_cache(vsr_handle* h, float* buffer, size_t n_floats, void* stream);
 
+/* ---- bf16 throughput mode (BASELINE configs[3]; never the parity path) -----------------------------------
+ * The reference is fp32 throughout (init_state hard-codes float32, controllable_captioning.py:109-115); token parity and the
+ * 1e-4 loss bound are fp32 claims.  This mode trades them for speed: every matrix product takes bf16 operands
+ * (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; states, activations, reductions, losses, gradients and the master
+ * weights stay fp32.  vsr_refresh_bf16_weights(h, buffer, ...) converts the 14 weight matrices into the caller's buffer
+ * (vsr_bf16_weight_bytes) and switches the handle to bf16; call it again after every weight update (the copies are not
+ * borrowed views).  buffer = NULL switches back to fp32.  Sizes must be multiples of 8 in this mode. */
+size_t vsr_bf16_weight_bytes(const vsr_handle* h);
+int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream);
+
 /* ---- workspace ------------------------------------------------------------------------------------ */
 /* bytes needed for B images with L slots of R regions, R0 pooled regions, decoding with up to `beam`
  * hypotheses per image (1 for greedy / sampling / teacher forcing). */
@@ -228,6 +238,8 @@ int vsr_profile_begin(vsr_handle* h);
  * vsr_profile_end() then reports the timed launches only (their count, summed duration and flops). */
 int vsr_profile_begin_sampled(vsr_handle* h, int32_t every);
 int64_t vsr_profile_seen(const vsr_handle* h);
+/* ALGORITHMIC bytes of the timed launches so far (operands + outputs once each; bf16 W copies count 2 bytes per element) */
+double vsr_profile_bytes(const vsr_handle* h);
 int vsr_profile_end(vsr_handle* h, void* stream, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
 
 #ifdef __cplusplus

@@ -43,7 +43,9 @@ def main():
     cfg = CFG
     w = synth.make_weights(cfg["V"], cfg["D"], cfg["E"], cfg["H"], cfg["A"], seed=2, gains={k: 1.5 for k in synth.DEFAULT_GAINS})
     m = helpers.build_model(cfg, w, dev).train()
-    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    # plain SGD: the update is linear in the gradient, so "N ranks == 1 rank" is tested on the exchange itself (Adam's
+    # g / (|g| + eps) turns a 1e-9 rounding difference of a near-zero gradient into a 1e-4 difference of the weight)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
     det, seq, caps, gts = helpers.train_inputs(cfg, 9)
     d2, c2 = helpers.decode_inputs(cfg, 10)
     lo, hi = parallel.shard_bounds(cfg["B"], a.world, a.rank)

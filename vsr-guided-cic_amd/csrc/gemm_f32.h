@@ -667,14 +667,14 @@ void gemm_nt_f32_r16_kernel(const GemmArgs args) {
 //   slots      resident workgroups the launch should fill (CUs x 4 for this 36.9 KB-LDS kernel)
 //   min_iters  smallest range worth a workgroup (prologue + flush amortisation)
 // Returns nslab; the caller then sets every problem's C / slab_stride (slabs are nslab deep).
-inline int gemm_plan(GemmArgs& a, int slots, int min_iters = 8, int BM = 64, int BN = 64) {
+inline int gemm_plan(GemmArgs& a, int slots, int min_iters = 8, int BM = 64, int BN = 64, int BK = GEMM_BK) {
     int total = 0, kt_max = 1;
     for (int i = 0; i < a.nprob; ++i) {
         GemmProb& p = a.p[i];
         p.tiles_m = (p.M + BM - 1) / BM;
         p.tiles_n = (p.N + BN - 1) / BN;
         p.ktiles = 0;
-        for (int s = 0; s < p.nseg; ++s) p.ktiles += (p.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+        for (int s = 0; s < p.nseg; ++s) p.ktiles += (p.seg[s].K + BK - 1) / BK;
         p.it_begin = total;
         total += p.tiles_m * p.tiles_n * p.ktiles;
         if (p.ktiles > kt_max) kt_max = p.ktiles;
@@ -697,6 +697,17 @@ inline double gemm_flops(const GemmArgs& a) {
     for (int i = 0; i < a.nprob; ++i)
         for (int s = 0; s < a.p[i].nseg; ++s) f += 2.0 * a.p[i].M * a.p[i].N * a.p[i].seg[s].K;
     return f;
+}
+
+// ALGORITHMIC bytes of a launch: every operand element and every output element once (w_bytes = bytes per weight element:
+// 4, or 2 when the W operands are bf16 copies); gathered A rows count once per output row.
+inline double gemm_bytes(const GemmArgs& a, int w_bytes) {
+    double b = 0;
+    for (int i = 0; i < a.nprob; ++i) {
+        b += 4.0 * a.p[i].M * a.p[i].N;
+        for (int s = 0; s < a.p[i].nseg; ++s) b += 4.0 * a.p[i].M * a.p[i].seg[s].K + (double)w_bytes * a.p[i].N * a.p[i].seg[s].K;
+    }
+    return b;
 }
 
 }  // namespace vsr

@@ -400,6 +400,10 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
 #pragma unroll
             for (int q = 0; q < QN; ++q) {
                 const int r = r0 + NW * q;
+                // a padding row's score never reaches the output (alpha = mask * softmax = 0, and the shift logit sums
+                // mask * z): its 512 tanh are skipped (wave-uniform: a wave owns whole rows); its z stays 0
+                const bool live = r < R + 1 && (r >= R || mk_row[r] != 0.f);
+                if (!live) continue;
                 const float4 w = (r < R) ? wa : ws;
                 sc[q] += w.x * tanhf(p[q].x + h.x);
                 sc[q] += w.y * tanhf(p[q].y + h.y);
@@ -1089,36 +1093,54 @@ __global__ __launch_bounds__(64) void k_select_beam(int t, int cb, int beam, int
 }
 
 // final ordering by sequence log-prob + back-tracking through the parent pointers      (:182-194)
-__global__ void k_backtrack(int T, int B, int beam, int out_size, const float* __restrict__ seq,
-                            const int* __restrict__ hist_parent, const int* __restrict__ hist_word,
-                            const int* __restrict__ hist_gate, const float* __restrict__ hist_lpw,
-                            const float* __restrict__ hist_lpg, int64_t* __restrict__ words, int64_t* __restrict__ gates,
-                            float* __restrict__ lp_w, float* __restrict__ lp_g, float* __restrict__ scores) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    int order[KMAX];
-    for (int q = 0; q < beam; ++q) order[q] = q;
-    for (int a = 1; a < beam; ++a) {          // stable insertion sort, descending
-        const int oa = order[a];
-        const float va = seq[b * beam + oa];
-        int p = a - 1;
-        while (p >= 0 && seq[b * beam + order[p]] < va) { order[p + 1] = order[p]; --p; }
-        order[p + 1] = oa;
+// One wave per image.  The image's whole history (T x beam parents / words / gates, strided by B * beam in global memory)
+// is fetched with independent loads into LDS first: the walk itself is then T dependent LDS reads instead of T dependent
+// global round trips per thread (a thread-per-image walk took 31 us for 100 images).
+__global__ __launch_bounds__(64) void k_backtrack(int T, int B, int beam, int out_size, const float* __restrict__ seq,
+                                                  const int* __restrict__ hist_parent, const int* __restrict__ hist_word,
+                                                  const int* __restrict__ hist_gate, const float* __restrict__ hist_lpw,
+                                                  const float* __restrict__ hist_lpg, int64_t* __restrict__ words, int64_t* __restrict__ gates,
+                                                  float* __restrict__ lp_w, float* __restrict__ lp_g, float* __restrict__ scores) {
+    extern __shared__ int bt[];                  // [3][T][beam]: parent, word, gate of this image
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = T * beam;
+    int* par = bt;
+    int* wrd = bt + n;
+    int* gat = bt + 2 * n;
+    for (int i = lane; i < n; i += 64) {
+        const int t = i / beam, q = i - t * beam;
+        const long long hrow = (long long)t * B * beam + b * beam + q;
+        par[i] = hist_parent[hrow];
+        wrd[i] = hist_word[hrow];
+        gat[i] = hist_gate[hrow];
     }
-    for (int o = 0; o < out_size; ++o) {
-        int q = order[o];
-        const long long dst = ((long long)b * out_size + o) * T;
-        if (scores) scores[b * out_size + o] = seq[b * beam + q];
-        for (int t = 0; t < T; ++t) {           // per-slot log-probs follow the final SLOT, not the ancestry
-            const long long hrow = (long long)t * B * beam + b * beam + order[o];
-            if (lp_w) lp_w[dst + t] = hist_lpw[hrow];
-            if (lp_g) lp_g[dst + t] = hist_lpg[hrow];
+    __shared__ int order[KMAX];
+    if (lane == 0) {
+        for (int q = 0; q < beam; ++q) order[q] = q;
+        for (int a = 1; a < beam; ++a) {          // stable insertion sort, descending
+            const int oa = order[a];
+            const float va = seq[b * beam + oa];
+            int p = a - 1;
+            while (p >= 0 && seq[b * beam + order[p]] < va) { order[p + 1] = order[p]; --p; }
+            order[p + 1] = oa;
         }
+    }
+    __syncthreads();
+    for (int i = lane; i < out_size * T; i += 64) {   // per-slot log-probs follow the final SLOT, not the ancestry
+        const int o = i / T, t = i - o * T;
+        const long long hrow = (long long)t * B * beam + b * beam + order[o];
+        const long long dst = ((long long)b * out_size + o) * T + t;
+        if (lp_w) lp_w[dst] = hist_lpw[hrow];
+        if (lp_g) lp_g[dst] = hist_lpg[hrow];
+    }
+    if (lane < out_size) {
+        int q = order[lane];
+        const long long dst = ((long long)b * out_size + lane) * T;
+        if (scores) scores[b * out_size + lane] = seq[b * beam + q];
         for (int t = T - 1; t >= 0; --t) {
-            const long long hrow = (long long)t * B * beam + b * beam + q;
-            words[dst + t] = hist_word[hrow];
-            gates[dst + t] = hist_gate[hrow];
-            q = hist_parent[hrow];
+            words[dst + t] = wrd[t * beam + q];
+            gates[dst + t] = gat[t * beam + q];
+            q = par[t * beam + q];
         }
     }
 }

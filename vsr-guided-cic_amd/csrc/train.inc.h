@@ -36,9 +36,13 @@ struct TrainCtx {
     size_t scratch_floats = 0;
     char* tpad_begin = nullptr;        // transposed-activation region (zeroed when its rows are padded)
     size_t tpad_bytes = 0;
+    // bf16 mode: every transposed operand that a GEMM takes as W (transposed weights, transposed activations of the
+    // weight-gradient products) has a bf16 twin the transposing kernels write instead of the fp32 buffer
+    struct Twin { const float* f; size_t n; uint16_t* b; };
+    std::vector<Twin> twins;
 };
 
-static inline size_t up4(size_t x) { return (x + 3) & ~size_t(3); }
+static inline size_t up4(size_t x) { return (x + 7) & ~size_t(7); }   // K paddings: multiples of 8 (16-byte bf16 chunks; fp32 needs 4)
 
 static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     const vsr_dims& d = h->d;
@@ -71,6 +75,11 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.wT_ih2 = b.take<float>(in2 * 4 * H); t.wT_hh2 = b.take<float>(H * 4 * H);
     t.wT_hg = b.take<float>(H * H); t.wT_ha = b.take<float>(H * A); t.wT_sfc = b.take<float>(H * D);
     t.wT_sa = b.take<float>(H * A); t.wT_ga = b.take<float>(H * A); t.wT_out = b.take<float>(H * up4(V));
+    t.twins.clear();
+    auto twin = [&](const float* f, size_t n) { t.twins.push_back(TrainCtx::Twin{f, n, b.take<uint16_t>(n)}); };
+    twin(t.wT_ih1, in1 * 4 * H); twin(t.wT_is, in1 * H); twin(t.wT_ig, in1 * H); twin(t.wT_hh1, H * 4 * H); twin(t.wT_hs, H * H);
+    twin(t.wT_ih2, in2 * 4 * H); twin(t.wT_hh2, H * 4 * H); twin(t.wT_hg, H * H); twin(t.wT_ha, H * A); twin(t.wT_sfc, H * D);
+    twin(t.wT_sa, H * A); twin(t.wT_ga, H * A); twin(t.wT_out, H * up4(V));
     b.off = (b.off + 255) & ~size_t(255);
     const size_t tp0 = b.off;
     t.tX_h2prev = b.take<float>(H * TBp); t.tX_x = b.take<float>(E * TBp); t.tX_h1prev = b.take<float>(H * TBp);
@@ -80,6 +89,8 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.tY_dpre1 = b.take<float>(6 * H * TBp); t.tY_dpre2 = b.take<float>(4 * H * TBp); t.tY_dlogits = b.take<float>(V * TBp);
     t.tY_dhA = b.take<float>(A * TBp); t.tY_dsent = b.take<float>(D * TBp); t.tY_dsa = b.take<float>(A * TBp); t.tY_dga = b.take<float>(A * TBp);
     t.tY_dpre1sum = b.take<float>(6 * H * Bp); t.tY_dpre2sum = b.take<float>(4 * H * Bp); t.tY_dP = b.take<float>(A * RLp);
+    twin(t.tX_h2prev, H * TBp); twin(t.tX_x, E * TBp); twin(t.tX_h1prev, H * TBp); twin(t.tX_h1, H * TBp); twin(t.tX_att, D * TBp);
+    twin(t.tX_st, H * TBp); twin(t.tX_gt, H * TBp); twin(t.tX_h2, H * TBp); twin(t.tX_vbar, D * Bp); twin(t.tX_reg, D * RLp);
     t.tpad_begin = base ? base + tp0 : nullptr;
     t.tpad_bytes = b.off - tp0;
     // GEMM slab scratch: 8 slabs of the largest product of the training path
@@ -114,8 +125,11 @@ static void colsum(TrainCtx& t, hipStream_t s, const float* X, long long ld, int
     hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), COLSUM_CHUNKS), dim3(256), 0, s, X, ld, R, C, t.scratch);
     hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(C, 256)), dim3(256), 0, s, t.scratch, C, out);
 }
-static void transpose(hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out) {
-    hipLaunchKernelGGL(k_transpose, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, in, ld_in, R, C, out, ld_out);
+// out = in^T; in the bf16 mode a buffer with a registered bf16 twin (a GEMM W operand) receives bf16 in the twin instead
+static void transpose(vsr_handle* h, hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out) {
+    uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(out)) : nullptr;
+    if (tw) hipLaunchKernelGGL(k_transpose_bf16, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, in, ld_in, R, C, tw, ld_out, out);
+    else hipLaunchKernelGGL(k_transpose, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, in, ld_in, R, C, out, ld_out);
 }
 
 extern "C" size_t vsr_train_workspace_bytes(const vsr_handle* h, int32_t B, int32_t T) {
@@ -144,6 +158,8 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     t.B = B; t.T = T;
     const size_t need = carve_train(h, t, reinterpret_cast<char*>(train_ws));
     if (need > train_ws_bytes) return fail("vsr_train_forward: training workspace too small (%zu < %zu)", train_ws_bytes, need);
+    h->b16.resize(h->b16_weights);                         // (re)register the bf16 twins of this workspace
+    for (const TrainCtx::Twin& tw : t.twins) h->b16.push_back(Bf16Range{tw.f, tw.f + tw.n, tw.b});
     const int TB = T * B;
     const size_t BH = (size_t)B * H;
     HIPCHK(hipMemsetAsync(t.h1s, 0, BH * sizeof(float), s));
@@ -331,21 +347,24 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         if (!G[i]) return fail("vsr_train_backward: gradient pointer %d is null", i);
 
     // ---- transposed weights (the optimizer may have changed them since the last call)
-    transpose(s, w.lstm1_weight_ih, in1, 4 * H, in1, t.wT_ih1, 4 * H);
-    transpose(s, w.W1_is_weight, in1, H, in1, t.wT_is, H);
-    transpose(s, w.W1_ig_weight, in1, H, in1, t.wT_ig, H);
-    transpose(s, w.lstm1_weight_hh, H, 4 * H, H, t.wT_hh1, 4 * H);
-    transpose(s, w.W1_hs_weight, H, H, H, t.wT_hs, H);
-    transpose(s, w.lstm2_weight_ih, in2, 4 * H, in2, t.wT_ih2, 4 * H);
-    transpose(s, w.lstm2_weight_hh, H, 4 * H, H, t.wT_hh2, 4 * H);
-    transpose(s, w.W1_hg_weight, H, H, H, t.wT_hg, H);
-    transpose(s, w.att_ha_weight, H, A, H, t.wT_ha, A);
-    transpose(s, w.s_fc_weight, H, D, H, t.wT_sfc, D);
-    transpose(s, w.att_sa_weight, H, A, H, t.wT_sa, A);
-    transpose(s, w.att_ga_weight, H, A, H, t.wT_ga, A);
-    const int Vp = (int)up4(V);        // K of the dh2_vocab GEMM must be a multiple of 4: zero-padded columns
-    if (Vp != V) HIPCHK(hipMemsetAsync(t.wT_out, 0, (size_t)H * Vp * sizeof(float), s));
-    transpose(s, w.out_fc_weight, H, V, H, t.wT_out, Vp);
+    transpose(h, s, w.lstm1_weight_ih, in1, 4 * H, in1, t.wT_ih1, 4 * H);
+    transpose(h, s, w.W1_is_weight, in1, H, in1, t.wT_is, H);
+    transpose(h, s, w.W1_ig_weight, in1, H, in1, t.wT_ig, H);
+    transpose(h, s, w.lstm1_weight_hh, H, 4 * H, H, t.wT_hh1, 4 * H);
+    transpose(h, s, w.W1_hs_weight, H, H, H, t.wT_hs, H);
+    transpose(h, s, w.lstm2_weight_ih, in2, 4 * H, in2, t.wT_ih2, 4 * H);
+    transpose(h, s, w.lstm2_weight_hh, H, 4 * H, H, t.wT_hh2, 4 * H);
+    transpose(h, s, w.W1_hg_weight, H, H, H, t.wT_hg, H);
+    transpose(h, s, w.att_ha_weight, H, A, H, t.wT_ha, A);
+    transpose(h, s, w.s_fc_weight, H, D, H, t.wT_sfc, D);
+    transpose(h, s, w.att_sa_weight, H, A, H, t.wT_sa, A);
+    transpose(h, s, w.att_ga_weight, H, A, H, t.wT_ga, A);
+    const int Vp = (int)up4(V);        // K of the dh2_vocab GEMM must be a multiple of 8: zero-padded columns
+    if (Vp != V) {
+        HIPCHK(hipMemsetAsync(t.wT_out, 0, (size_t)H * Vp * sizeof(float), s));
+        if (uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(t.wT_out)) : nullptr) HIPCHK(hipMemsetAsync(tw, 0, (size_t)H * Vp * sizeof(uint16_t), s));
+    }
+    transpose(h, s, w.out_fc_weight, H, V, H, t.wT_out, Vp);
     HIPCHK(hipMemsetAsync(t.dP, 0, (size_t)RL * A * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dh1_c, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dh2_c, 0, BH * sizeof(float), s));
@@ -484,26 +503,30 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     const float* h1cur = t.h1s + BH;
     const float* h2prev = t.h2s;
     const float* h2cur = t.h2s + BH;
-    transpose(s, h2prev, H, TB, H, t.tX_h2prev, TBp);
-    transpose(s, t.x_all, E, TB, E, t.tX_x, TBp);
-    transpose(s, h1prev, H, TB, H, t.tX_h1prev, TBp);
-    transpose(s, h1cur, H, TB, H, t.tX_h1, TBp);
-    transpose(s, t.atts, D, TB, D, t.tX_att, TBp);
-    transpose(s, t.s_ts, H, TB, H, t.tX_st, TBp);
-    transpose(s, t.g_ts, H, TB, H, t.tX_gt, TBp);
-    transpose(s, h2cur, H, TB, H, t.tX_h2, TBp);
-    transpose(s, c.vbar, D, B, D, t.tX_vbar, Bp);
-    if (NV > 0) hipLaunchKernelGGL(k_transpose_gather, dim3(cdiv(D, 32), cdiv(NV, 32)), dim3(256), 0, s, c.regions, (long long)D, c.vlist, NV, D, t.tX_reg, (long long)NVp);
-    transpose(s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp);
-    transpose(s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp);
-    transpose(s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp);
-    transpose(s, t.dhA_all, A, TB, A, t.tY_dhA, TBp);
-    transpose(s, t.dsent_all, D, TB, D, t.tY_dsent, TBp);
-    transpose(s, t.dsa_all, A, TB, A, t.tY_dsa, TBp);
-    transpose(s, t.dga_all, A, TB, A, t.tY_dga, TBp);
+    transpose(h, s, h2prev, H, TB, H, t.tX_h2prev, TBp);
+    transpose(h, s, t.x_all, E, TB, E, t.tX_x, TBp);
+    transpose(h, s, h1prev, H, TB, H, t.tX_h1prev, TBp);
+    transpose(h, s, h1cur, H, TB, H, t.tX_h1, TBp);
+    transpose(h, s, t.atts, D, TB, D, t.tX_att, TBp);
+    transpose(h, s, t.s_ts, H, TB, H, t.tX_st, TBp);
+    transpose(h, s, t.g_ts, H, TB, H, t.tX_gt, TBp);
+    transpose(h, s, h2cur, H, TB, H, t.tX_h2, TBp);
+    transpose(h, s, c.vbar, D, B, D, t.tX_vbar, Bp);
+    if (NV > 0) {
+        uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(t.tX_reg)) : nullptr;
+        if (tw) hipLaunchKernelGGL(k_transpose_gather_bf16, dim3(cdiv(D, 32), cdiv(NV, 32)), dim3(256), 0, s, c.regions, (long long)D, c.vlist, NV, D, tw, (long long)NVp, t.tX_reg);
+        else hipLaunchKernelGGL(k_transpose_gather, dim3(cdiv(D, 32), cdiv(NV, 32)), dim3(256), 0, s, c.regions, (long long)D, c.vlist, NV, D, t.tX_reg, (long long)NVp);
+    }
+    transpose(h, s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp);
+    transpose(h, s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp);
+    transpose(h, s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp);
+    transpose(h, s, t.dhA_all, A, TB, A, t.tY_dhA, TBp);
+    transpose(h, s, t.dsent_all, D, TB, D, t.tY_dsent, TBp);
+    transpose(h, s, t.dsa_all, A, TB, A, t.tY_dsa, TBp);
+    transpose(h, s, t.dga_all, A, TB, A, t.tY_dga, TBp);
     if (NV > 0) hipLaunchKernelGGL(k_transpose_gather, dim3(cdiv(A, 32), cdiv(NV, 32)), dim3(256), 0, s, t.dP, (long long)A, c.vlist, NV, A, t.tY_dP, (long long)NVp);
     hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 6 * H, 256)), dim3(256), 0, s, t.dpre1, T, (long long)B * 6 * H, t.dpre1sum);
-    transpose(s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
+    transpose(h, s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
     LAUNCHCHK();
 
     // Gradients are finished bucket by bucket, largest first, and an event is recorded after each bucket
@@ -528,7 +551,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2)) return 1;
     if (d.img_second_lstm) {
         hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 4 * H, 256)), dim3(256), 0, s, t.dpre2, T, (long long)B * 4 * H, t.dpre2sum);
-        transpose(s, t.dpre2sum, 4 * H, B, 4 * H, t.tY_dpre2sum, Bp);
+        transpose(h, s, t.dpre2sum, 4 * H, B, 4 * H, t.tY_dpre2sum, Bp);
         if (gemm_to1(h, t, s, 4 * H, D, Bp, t.tY_dpre2sum, Bp, t.tX_vbar, Bp, G[g_Wih2] + H + D, in2)) return 1;
     }
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H)) return 1;

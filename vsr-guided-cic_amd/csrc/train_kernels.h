@@ -24,6 +24,43 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in,
         if (c0 + i < C && r0 + tx < R) out[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
 }
 
+// the same, written as bf16 (round-to-nearest-even): the bf16 mode's W operands (gemm_bf16.h)
+__device__ __forceinline__ uint16_t to_bf16_bits(float x) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {x, 0.f};
+    return (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2)) & 0xffffu);
+}
+// (the fp32 image is written too: a launch that cannot take the bf16 kernel - odd alignment - falls back to the fp32 one)
+__global__ __launch_bounds__(256) void k_transpose_bf16(const float* __restrict__ in, long long ld_in, int R, int C,
+                                                        uint16_t* __restrict__ out, long long ld_out, float* __restrict__ out32) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) t[i][tx] = in[(long long)(r0 + i) * ld_in + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) {
+            out[(long long)(c0 + i) * ld_out + r0 + tx] = to_bf16_bits(t[tx][i]);
+            out32[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
+        }
+}
+__global__ __launch_bounds__(256) void k_transpose_gather_bf16(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int n,
+                                                               int C, uint16_t* __restrict__ out, long long ld_out, float* __restrict__ out32) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < n && c0 + tx < C) t[i][tx] = in[(long long)list[r0 + i] * ld_in + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < n) {
+            out[(long long)(c0 + i) * ld_out + r0 + tx] = to_bf16_bits(t[tx][i]);
+            out32[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
+        }
+}
+
 // out (C, n) = rows list[0..n) of in (., C), transposed: out[c][j] = in[list[j]][c]
 __global__ __launch_bounds__(256) void k_transpose_gather(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int n,
                                                           int C, float* __restrict__ out, long long ld_out) {

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "gemm_f32.h"
+#include "gemm_bf16.h"
 #include "kernels.h"
 #include "train_kernels.h"
 
@@ -79,8 +80,20 @@ static TrainCtx* new_train_ctx();
 static void free_train_ctx(TrainCtx*);
 static void invalidate_train_ctx(TrainCtx*);
 
+struct Bf16Range { const float* lo; const float* hi; const uint16_t* b; };   // fp32 matrix [lo, hi) has a bf16 copy at b
+
 struct vsr_handle {
     TrainCtx* tc = nullptr;
+    // bf16 throughput mode (gemm_bf16.h): off unless vsr_refresh_bf16_weights() has been given a buffer
+    bool bf16_on = false;
+    std::vector<Bf16Range> b16;        // weights (refresh) + the training pass's transposed operands (carve_train)
+    size_t b16_weights = 0;            // entries of b16 that belong to the weights
+    int gemm_slots_bf16 = 256;         // ONE 8-wave workgroup per CU (108 KB of LDS: two 128+256-row x 64-k bf16 buffers)
+    const uint16_t* map16(const float* p) const {
+        for (const Bf16Range& r : b16)
+            if (p >= r.lo && p < r.hi) return r.b + (p - r.lo);
+        return nullptr;
+    }
     vsr_dims d;
     vsr_weights w;
     bool bound = false, prepared = false;
@@ -107,7 +120,7 @@ struct vsr_handle {
     int* host_back = nullptr;        // pinned landing place of that read-back (2 ints)
     std::vector<hipEvent_t> ev;      // pool, pairs (start, stop)
     size_t ev_used = 0;
-    double prof_flops = 0;
+    double prof_flops = 0, prof_bytes = 0;
     int prof_every = 1;              // time every prof_every-th GEMM launch (1 = all of them)
     long long prof_seen = 0;         // GEMM launches since vsr_profile_begin*
 };
@@ -207,6 +220,24 @@ struct GemmBuilder {
     int finish(const vsr_handle* h) {
         int maxM = 0;
         for (int i = 0; i < a.nprob; ++i) maxM = std::max(maxM, a.p[i].M);
+        if (h->bf16_on) {
+            // bf16 mode: every W operand of the launch must have a bf16 copy (and 16-byte-aligned 8-element chunks);
+            // a launch that does not qualify runs on the fp32 kernel
+            bool ok = true;
+            for (int i = 0; i < a.nprob && ok; ++i)
+                for (int sg = 0; sg < a.p[i].nseg && ok; ++sg) {
+                    const GemmSeg& S = a.p[i].seg[sg];
+                    const uint16_t* w16 = h->map16(S.W);
+                    ok = w16 && (S.K % 8 == 0) && (S.ldw % 8 == 0) && (S.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(w16) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(S.A) & 15) == 0);
+                }
+            if (ok) {
+                for (int i = 0; i < a.nprob; ++i)
+                    for (int sg = 0; sg < a.p[i].nseg; ++sg) a.p[i].seg[sg].W = reinterpret_cast<const float*>(h->map16(a.p[i].seg[sg].W));
+                big = 32;
+                return gemm_plan(a, h->gemm_slots_bf16, 4, 128, 256, B16_BK);
+            }
+        }
         big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM >= 1024 ? 2 : maxM > 192 ? 1 : 0);
         if (h->gemm_tile == 0 && maxM <= h->gemm_r16_max) {
             // short problems: every row of an m-tile in one workgroup, rows in units of 16 (M = 100 -> 112, not 128)
@@ -225,10 +256,11 @@ struct GemmBuilder {
 };
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
-    dim3 grid(((a.G + 7) / 8) * 8), block(big == 16 ? 512 : 256);
+    dim3 grid(((a.G + 7) / 8) * 8), block(big == 16 || big == 32 ? 512 : 256);
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
-    if (big == 16) {
+    if (big == 32) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<2, 4, 2, 2>), grid, block, 0, s, a);
+    else if (big == 16) {
         switch (r16_tm) {
             case 1: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<1, 2>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<2, 2>), grid, block, 0, s, a); break;
@@ -246,6 +278,7 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
         (void)hipEventRecord(h->ev[h->ev_used + 1], s);
         h->ev_used += 2;
         h->prof_flops += gemm_flops(a);
+        h->prof_bytes += gemm_bytes(a, big == 32 ? 2 : 4);
     }
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -276,7 +309,9 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
         h->gemm_slots = prop.multiProcessorCount * 4;
         h->gemm_slots_small = prop.multiProcessorCount * 3;
         h->gemm_slots_r16 = prop.multiProcessorCount;
+        h->gemm_slots_bf16 = prop.multiProcessorCount;
     }
+    if (const char* e = getenv("VSR_GEMM_SLOTS_BF16")) h->gemm_slots_bf16 = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_R16")) h->gemm_slots_r16 = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_R16_MAX")) h->gemm_r16_max = atoi(e);
     if (const char* e = getenv("VSR_GEMM_SLOTS")) h->gemm_slots = std::max(1, atoi(e));
@@ -300,6 +335,7 @@ extern "C" int vsr_profile_begin_sampled(vsr_handle* h, int32_t every);
 extern "C" int vsr_profile_begin(vsr_handle* h) { return vsr_profile_begin_sampled(h, 1); }
 
 extern "C" int64_t vsr_profile_seen(const vsr_handle* h) { return h ? (int64_t)h->prof_seen : 0; }
+extern "C" double vsr_profile_bytes(const vsr_handle* h) { return h ? h->prof_bytes : 0.0; }
 
 extern "C" int vsr_profile_begin_sampled(vsr_handle* h, int32_t every) {
     if (!h) return fail("vsr_profile_begin: null handle");
@@ -314,6 +350,7 @@ extern "C" int vsr_profile_begin_sampled(vsr_handle* h, int32_t every) {
     }
     h->ev_used = 0;
     h->prof_flops = 0;
+    h->prof_bytes = 0;
     h->profiling = true;
     return 0;
 }
@@ -342,6 +379,11 @@ extern "C" int vsr_bind_weights(vsr_handle* h, const vsr_weights* w) {
     h->w = *w;
     h->bound = true;
     h->xproj = nullptr;               // a cache built for other weight pointers is void
+    if (h->bf16_on) {                 // ... and so are the bf16 copies: back to fp32 until vsr_refresh_bf16_weights is called again
+        h->bf16_on = false;
+        h->b16.erase(h->b16.begin(), h->b16.begin() + h->b16_weights);
+        h->b16_weights = 0;
+    }
     return 0;
 }
 
@@ -380,6 +422,65 @@ extern "C" int vsr_build_decode_cache(vsr_handle* h, float* buf, size_t n_floats
     }
     LAUNCHCHK();
     h->xproj = buf;
+    return 0;
+}
+
+// ---- bf16 throughput mode: bf16 copies of the 14 weight matrices the GEMMs multiply by (fp32 stays the master copy)
+static const int B16_NW = 14;
+static void b16_weight_list(const vsr_handle* h, const float* (&ptr)[B16_NW], size_t (&n)[B16_NW]) {
+    const vsr_dims& d = h->d;
+    const vsr_weights& w = h->w;
+    const size_t H = d.rnn_size, A = d.att_size, D = d.det_feat_size, E = d.input_encoding_size, V = d.vocab_size;
+    const size_t in1 = (d.h2_first_lstm ? H : 0) + D + E, in2 = H + D + (d.img_second_lstm ? D : 0);
+    const float* p[B16_NW] = {w.W1_is_weight, w.W1_hs_weight, w.att_va_weight, w.att_ha_weight, w.att_sa_weight, w.lstm1_weight_ih,
+                              w.lstm1_weight_hh, w.lstm2_weight_ih, w.lstm2_weight_hh, w.out_fc_weight, w.s_fc_weight, w.W1_ig_weight,
+                              w.W1_hg_weight, w.att_ga_weight};
+    const size_t c[B16_NW] = {H * in1, H * H, A * D, A * H, A * H, 4 * H * in1, 4 * H * H, 4 * H * in2, 4 * H * H, V * H, D * H, H * in1, H * H, A * H};
+    for (int i = 0; i < B16_NW; ++i) { ptr[i] = p[i]; n[i] = c[i]; }
+}
+extern "C" size_t vsr_bf16_weight_bytes(const vsr_handle* h) {
+    if (!h) return 0;
+    const float* p[B16_NW]; size_t n[B16_NW];
+    vsr_handle tmp_dims;                       // only the sizes are needed (pointers may be unbound)
+    tmp_dims.d = h->d;
+    memset(&tmp_dims.w, 0, sizeof(tmp_dims.w));
+    b16_weight_list(&tmp_dims, p, n);
+    size_t tot = 0;
+    for (int i = 0; i < B16_NW; ++i) tot += ((n[i] + 7) & ~size_t(7)) * sizeof(uint16_t);
+    return tot + 256;
+}
+extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream) {
+    if (!h) return fail("vsr_refresh_bf16_weights: null handle");
+    if (!buffer) {                                          // back to the fp32 parity mode
+        h->bf16_on = false;
+        h->b16.resize(0);
+        h->b16_weights = 0;
+        h->xproj = nullptr;                                 // a decode cache built in the other precision is void
+        return 0;
+    }
+    if (!h->bound) return fail("vsr_refresh_bf16_weights: weights not bound");
+    const vsr_dims& d = h->d;
+    if (d.det_feat_size % 8 || d.input_encoding_size % 8 || d.rnn_size % 8 || d.att_size % 8)
+        return fail("vsr_refresh_bf16_weights: the bf16 mode needs det_feat_size, input_encoding_size, rnn_size and att_size to be "
+                    "multiples of 8 (16-byte bf16 chunks); got %d %d %d %d", d.det_feat_size, d.input_encoding_size, d.rnn_size, d.att_size);
+    if (bytes < vsr_bf16_weight_bytes(h)) return fail("vsr_refresh_bf16_weights: buffer too small");
+    if (reinterpret_cast<uintptr_t>(buffer) & 15) return fail("vsr_refresh_bf16_weights: buffer must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const float* p[B16_NW]; size_t n[B16_NW];
+    b16_weight_list(h, p, n);
+    std::vector<Bf16Range> keep(h->b16.begin() + h->b16_weights, h->b16.end());   // training operands registered by carve_train
+    h->b16.resize(0);
+    uint16_t* out = reinterpret_cast<uint16_t*>(buffer);
+    for (int i = 0; i < B16_NW; ++i) {
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3(cdiv((long long)n[i], 8 * 256)), dim3(256), 0, s, p[i], out, (long long)n[i]);
+        h->b16.push_back(Bf16Range{p[i], p[i] + n[i], out});
+        out += (n[i] + 7) & ~size_t(7);
+    }
+    h->b16_weights = h->b16.size();
+    h->b16.insert(h->b16.end(), keep.begin(), keep.end());
+    LAUNCHCHK();
+    if (!h->bf16_on) h->xproj = nullptr;
+    h->bf16_on = true;
     return 0;
 }
 
@@ -832,7 +933,7 @@ extern "C" int vsr_beam(vsr_handle* h, int32_t beam, int32_t out_size, int64_t e
 #undef SEL_ARGS
         LAUNCHCHK();
     }
-    hipLaunchKernelGGL(k_backtrack, dim3(cdiv(B, 64)), dim3(64), 0, s, T, B, beam, out_size, c.seq[T & 1], c.hist_parent, c.hist_word,
+    hipLaunchKernelGGL(k_backtrack, dim3(B), dim3(64), (size_t)3 * T * beam * sizeof(int), s, T, B, beam, out_size, c.seq[T & 1], c.hist_parent, c.hist_word,
                        c.hist_gate, c.hist_lpw, c.hist_lpg, words, gates, lp_words, lp_gates, scores);
     LAUNCHCHK();
     return 0;

@@ -69,6 +69,16 @@ class ControllableCaptioningModel(CaptioningModel):
         # set force_prepare = True when inputs / weights are rewritten in ways that do not bump _version
         # (t.data.copy_, DLPack / custom-kernel writes, p.data edits), or call invalidate_cache() after such a write
         self.force_prepare = False
+        self.compute_dtype = 'f32'
+
+    def set_compute_dtype(self, dtype):
+        """'f32' (default): the reference's precision, the mode token parity and the 1e-4 loss bound hold in.
+        'bf16': throughput mode - matrix products take bf16 operands with fp32 accumulation (v_mfma_f32_32x32x16_bf16);
+        parameters, optimizer state, states and reductions stay fp32.  Not a parity mode."""
+        if dtype not in ('f32', 'bf16'):
+            raise ValueError("compute dtype must be 'f32' or 'bf16'")
+        self.compute_dtype = dtype
+        return self
 
     def invalidate_cache(self):
         if self._eng is not None:
@@ -108,6 +118,7 @@ class ControllableCaptioningModel(CaptioningModel):
         if pdev.type != 'cuda' or (device.index is not None and pdev.index != device.index):
             raise RuntimeError("model parameters are on %s but the inputs are on %s" % (pdev, device))
         self._eng.bind(params)
+        self._eng.set_bf16(pdev, self._weights_version(), self.compute_dtype == 'bf16')
         # inference keeps a weight-only cache (embedding projection); while training the weights move every step
         self._eng.decode_cache(pdev, self._weights_version(), enable=not self.training)
         return self._eng

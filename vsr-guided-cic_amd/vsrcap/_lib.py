@@ -51,6 +51,8 @@ SIGNATURES = {
     "vsr_set_verb_table": (I32, [P, P, P, I32]),
     "vsr_decode_cache_floats": (SZ, [P]),
     "vsr_build_decode_cache": (I32, [P, P, SZ, P]),
+    "vsr_bf16_weight_bytes": (SZ, [P]),
+    "vsr_refresh_bf16_weights": (I32, [P, P, SZ, P]),
     "vsr_workspace_bytes": (SZ, [P, I32, I32, I32, I32, I32]),
     "vsr_prepare": (I32, [P, P, I32, I32, P, I32, I32, I32, P, SZ, P]),
     "vsr_workspace_bytes_indexed": (SZ, [P, I32, I32, I32, I32, I32, I32, I32]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "vsr_profile_begin": (I32, [P]),
     "vsr_profile_begin_sampled": (I32, [P, I32]),
     "vsr_profile_seen": (I64, [P]),
+    "vsr_profile_bytes": (C.c_double, [P]),
     "vsr_profile_end": (I32, [P, P, C.POINTER(C.c_double), C.POINTER(I64), C.POINTER(C.c_double)]),
     "vsr_step": (I32, [P, I32, I32, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, P, P, P]),
 }

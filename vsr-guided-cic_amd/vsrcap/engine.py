@@ -97,6 +97,7 @@ class Engine:
         buffer, p.data edits of the weights) are invisible to it - call this after such a write."""
         self._prep_key = None
         self._cache_key = None
+        self._bf16_key = None if getattr(self, "_bf16_key", None) is None else ()
 
     def raise_on_bad_ids(self, device, who):
         if not self.check_ids:
@@ -121,6 +122,26 @@ class Engine:
         fl = torch.tensor(flat if flat else [0], dtype=torch.int32, device=device)
         self._verb_dev = (rp, fl)
         _lib.check(self.lib.vsr_set_verb_table(self.h, _ptr(rp), _ptr(fl), n))
+
+    # ------------------------------------------------------------------ bf16 throughput mode
+    @_on_device
+    def set_bf16(self, device, weights_version, enable):
+        """enable: (re)build the bf16 copies of the weight matrices when the bound weights or their version changed and
+        switch the handle to bf16 GEMMs; disable: back to the fp32 parity mode (include/vsrcap.h, vsr_refresh_bf16_weights)."""
+        key = (self._bound_ptrs, weights_version) if enable else None
+        if key == getattr(self, "_bf16_key", None):
+            return
+        if not enable:
+            _lib.check(self.lib.vsr_refresh_bf16_weights(self.h, C.c_void_p(0), 0, self._stream(device)))
+        else:
+            n = self.lib.vsr_bf16_weight_bytes(self.h)
+            if getattr(self, "_bf16_buf", None) is None or self._bf16_buf.numel() < n or self._bf16_buf.device != device:
+                self._bf16_buf = torch.empty(n, dtype=torch.uint8, device=device)
+            _lib.check(self.lib.vsr_refresh_bf16_weights(self.h, _ptr(self._bf16_buf), self._bf16_buf.numel(), self._stream(device)))
+        if (key is None) != (getattr(self, "_bf16_key", None) is None):
+            self._cache_key = None               # the decode cache was built in the other precision
+            self._prep_key = None                # ... and so were the hoisted projections
+        self._bf16_key = key
 
     # ------------------------------------------------------------------ decode cache (inference only)
     @_on_device
@@ -303,6 +324,10 @@ class Engine:
 
     def profile_seen(self):
         return int(self.lib.vsr_profile_seen(self.h))
+
+    def profile_bytes(self):
+        """algorithmic bytes of the GEMM launches timed since profile_begin (read before profile_end)"""
+        return float(self.lib.vsr_profile_bytes(self.h))
 
     @_on_device
     def profile_end(self, device):
