@@ -228,6 +228,52 @@ int vsr_cider_rewards(const uint64_t* const* keys, const double* const* idf, con
                       const int64_t* cand, int32_t N, int32_t T, const int64_t* refs, int32_t n_ref, int32_t Tr,
                       int64_t eos, int64_t pad, const uint8_t* drop, int32_t V, double sigma, float* rewards, void* stream);
 
+/* ---- ordering models of the eval loop on the device ------------------------------------
+ * coco_scripts/eval_coco.py:127-221 calls, per caption and per verb, S_SSP.generate (models/sort_model.py:105-183, batch
+ * size 1: a 3+3-layer 512-d transformer that orders the verb's semantic roles by greedy "pick from the remaining roles")
+ * and, per repeated role, SinkhornNet (models/sinkhorn_network.py:39-51) followed by munkres on the transposed matrix
+ * (:185-189) - each with host round trips.  These entry points take ALL sequences / items of a loader batch at once.
+ * Weights: borrowed fp32 device pointers in the reference's [out, in] layout (state_dict names in the comments). */
+typedef struct vsr_ssp_layer {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ln3_w, *ln3_b;    /* layer_norm1..3 (ln3: decoder layers only)               */
+    const float *Wq, *bq, *Wk, *bk, *Wv, *bv, *Wo, *bo;             /* attention.linear_{Q,K,V,O}; the decoder's cross attention */
+                                                                    /* re-uses them (sort_modules.py:88), cross_attention.* is dead */
+    const float *W1, *b1, *W2, *b2;                                 /* ff_layer.w_1 (2048,512), w_2 (512,2048)                 */
+} vsr_ssp_layer;
+typedef struct vsr_ssp_weights {
+    const float* sr_embed;       /* sr_embed_layer.weight (26, 512)  (shared by encoder.* and decoder.embed_layer) */
+    const float* v_embed;        /* v_embed_layer.weight (n_verbs, 512) */
+    int64_t n_verbs;
+    const float *fc_w, *fc_b;    /* encoder.fc_feat */
+    vsr_ssp_layer enc[3];        /* encoder.encoder_layers.N */
+    const float *enc_ln_w, *enc_ln_b;
+    vsr_ssp_layer dec[3];        /* decoder.encoder_layers.N */
+    const float *dec_ln_w, *dec_ln_b;
+    const float *exp_w, *exp_b;  /* expander_nn (26, 512) */
+} vsr_ssp_weights;
+typedef struct vsr_sinkhorn_weights {
+    const float *W1_txt_w, *W1_txt_b, *W1_vis_w, *W1_vis_b, *W2_vis_w, *W2_vis_b, *W_fc_pos_w, *W_fc_pos_b, *W_fc_w, *W_fc_b;
+    int32_t N, n_iters;          /* SinkhornNet(N, n_iters, tau): eval_coco.py:101 uses (10, 20, 0.1) */
+    float tau;
+} vsr_sinkhorn_weights;
+typedef struct vsr_ssp vsr_ssp;
+int vsr_ssp_create(vsr_ssp** out);
+void vsr_ssp_destroy(vsr_ssp* e);
+int vsr_ssp_bind(vsr_ssp* e, const vsr_ssp_weights* ssp /* or NULL */, const vsr_sinkhorn_weights* sinkhorn /* or NULL */);
+size_t vsr_ssp_workspace_bytes(int32_t S);
+/* S_SSP.generate(verb, roles, mode='not-normal') for S sequences: verbs (S) int64, roles (S,10) int32 (0 = padding) ->
+ * pred (S,10) int32 (the roles in generated order, 0 beyond), logp (S,10) fp32 (the reference returns these truncated to
+ * integers, sort_model.py:121, and its callers ignore them). */
+int vsr_ssp_generate(vsr_ssp* e, const int64_t* verbs, const int32_t* roles, int32_t S, int32_t* pred, float* logp, void* workspace,
+                     size_t workspace_bytes, void* stream);
+size_t vsr_sinkhorn_workspace_bytes(int32_t Q, int32_t N);
+/* SinkhornNet.forward + assignment for Q items: seq (Q,N,2352) -> tr (Q,N,N) or NULL, assign (Q,N) int32 with
+ * assign[q][i] = the column munkres pairs with row i of tr[q]^T under cost max - value (eval_coco.py:185-189).
+ * munkres is not in the image: the kernel computes the optimum of that cost matrix (Kuhn-Munkres, fp64); parity of the
+ * assignment is pinned to the optimum, not to the package. */
+int vsr_sinkhorn_assign(vsr_ssp* e, const float* seq, int32_t Q, float* tr, int32_t* assign, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 /* ---- measurement (bench.py roofline leg) ------------------------------------------------------------ */
 /* Between begin and end every fp32-MFMA GEMM launch is bracketed by a pair of pre-created HIP events on the
  * caller's stream.  end() synchronises the stream and returns the summed launch durations, the number of

@@ -1007,6 +1007,7 @@ extern "C" int vsr_step(vsr_handle* h, int32_t t, int32_t rows_per_image, const 
 // ---------------------------------------------------------------------------------------------- training path
 #include "train.inc.h"
 #include "cider.inc.h"
+#include "ssp.inc.h"
 
 static TrainCtx* new_train_ctx() { return new TrainCtx(); }
 static void free_train_ctx(TrainCtx* t) { delete t; }

@@ -41,6 +41,27 @@ class VsrWeights(C.Structure):
 P = C.c_void_p
 I32, I64, U64, SZ = C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
 
+# ---- ordering models (include/vsrcap.h: vsr_ssp_layer / vsr_ssp_weights / vsr_sinkhorn_weights)
+SSP_LAYER_FIELDS = ["ln1_w", "ln1_b", "ln2_w", "ln2_b", "ln3_w", "ln3_b", "Wq", "bq", "Wk", "bk", "Wv", "bv", "Wo", "bo", "W1", "b1", "W2", "b2"]
+
+
+class VsrSspLayer(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in SSP_LAYER_FIELDS]
+
+
+class VsrSspWeights(C.Structure):
+    _fields_ = [("sr_embed", C.c_void_p), ("v_embed", C.c_void_p), ("n_verbs", C.c_int64), ("fc_w", C.c_void_p), ("fc_b", C.c_void_p),
+                ("enc", VsrSspLayer * 3), ("enc_ln_w", C.c_void_p), ("enc_ln_b", C.c_void_p), ("dec", VsrSspLayer * 3),
+                ("dec_ln_w", C.c_void_p), ("dec_ln_b", C.c_void_p), ("exp_w", C.c_void_p), ("exp_b", C.c_void_p)]
+
+
+SINKHORN_FIELDS = ["W1_txt_w", "W1_txt_b", "W1_vis_w", "W1_vis_b", "W2_vis_w", "W2_vis_b", "W_fc_pos_w", "W_fc_pos_b", "W_fc_w", "W_fc_b"]
+
+
+class VsrSinkhornWeights(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in SINKHORN_FIELDS] + [("N", C.c_int32), ("n_iters", C.c_int32), ("tau", C.c_float)]
+
+
 # name -> (restype, argtypes); must list every symbol include/vsrcap.h declares
 SIGNATURES = {
     "vsr_abi_version": (I32, []),
@@ -72,6 +93,13 @@ SIGNATURES = {
     "vsr_bad_ids": (I32, [P, C.POINTER(I32), P]),
     "vsr_debug_copy": (I32, [P, C.c_char_p, P, SZ, P]),
     "vsr_cider_rewards": (I32, [P, P, P, C.c_double, P, I32, I32, P, I32, I32, I64, I64, P, I32, C.c_double, P, P]),
+    "vsr_ssp_create": (I32, [C.POINTER(P)]),
+    "vsr_ssp_destroy": (None, [P]),
+    "vsr_ssp_bind": (I32, [P, C.POINTER(VsrSspWeights), C.POINTER(VsrSinkhornWeights)]),
+    "vsr_ssp_workspace_bytes": (SZ, [I32]),
+    "vsr_ssp_generate": (I32, [P, P, P, I32, P, P, P, SZ, P]),
+    "vsr_sinkhorn_workspace_bytes": (SZ, [I32, I32]),
+    "vsr_sinkhorn_assign": (I32, [P, P, I32, P, P, P, SZ, P]),
     "vsr_profile_begin": (I32, [P]),
     "vsr_profile_begin_sampled": (I32, [P, I32]),
     "vsr_profile_seen": (I64, [P]),

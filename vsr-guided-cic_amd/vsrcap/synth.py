@@ -191,3 +191,91 @@ def make_verb_table(n_verbs, V, seed=0):
         k = 1 if v == 2 else int(hash_int(1, 2, 7, 10 + v, seed)[0])
         table[str(v)] = [int(i) for i in hash_int(k, 1, V, 1000 + v, seed)]
     return table
+
+
+# ---------------------------------------------------------------------------------------------- ordering models
+def ssp_param_shapes(n_verbs=2663):
+    """state_dict keys / shapes of the reference's S_SSP (models/sort_model.py:13-52) in its own order, without the
+    positional-encoding / label-smoothing buffers."""
+    H, F_ = 512, 2048
+    sh = OrderedDict()
+    sh["sr_embed_layer.weight"] = (26, H)
+    sh["v_embed_layer.weight"] = (n_verbs, H)
+
+    def layer(pre, dec):
+        names = ["attention"] + (["cross_attention"] if dec else [])
+        for a in names:
+            for q in "QKVO":
+                sh["%s.%s.linear_%s.weight" % (pre, a, q)] = (H, H)
+                sh["%s.%s.linear_%s.bias" % (pre, a, q)] = (H,)
+        sh[pre + ".ff_layer.w_1.weight"] = (F_, H); sh[pre + ".ff_layer.w_1.bias"] = (F_,)
+        sh[pre + ".ff_layer.w_2.weight"] = (H, F_); sh[pre + ".ff_layer.w_2.bias"] = (H,)
+        for i in range(1, 4 if dec else 3):
+            sh["%s.layer_norm%d.weight" % (pre, i)] = (H,)
+            sh["%s.layer_norm%d.bias" % (pre, i)] = (H,)
+    sh["encoder.layer_norm.weight"] = (H,); sh["encoder.layer_norm.bias"] = (H,)
+    for l in range(3):
+        layer("encoder.encoder_layers.%d" % l, False)
+    sh["encoder.fc_feat.weight"] = (H, H); sh["encoder.fc_feat.bias"] = (H,)
+    sh["decoder.layer_norm.weight"] = (H,); sh["decoder.layer_norm.bias"] = (H,)
+    for l in range(3):
+        layer("decoder.encoder_layers.%d" % l, True)
+    sh["expander_nn.weight"] = (26, H); sh["expander_nn.bias"] = (26,)
+    return sh
+
+
+def sinkhorn_param_shapes(N=10):
+    """SinkhornNet (models/sinkhorn_network.py:5-16)"""
+    return OrderedDict([("W1_txt.weight", (128, 300)), ("W1_txt.bias", (128,)), ("W1_vis.weight", (512, 2048)), ("W1_vis.bias", (512,)),
+                        ("W2_vis.weight", (128, 512)), ("W2_vis.bias", (128,)), ("W_fc_pos.weight", (256, 260)), ("W_fc_pos.bias", (256,)),
+                        ("W_fc.weight", (N, 256)), ("W_fc.bias", (N,))])
+
+
+def _fill(shapes, seed, stream0, gain):
+    w = OrderedDict()
+    for i, (k, shp) in enumerate(shapes.items()):
+        n = int(np.prod(shp))
+        u = hash_u01(n, stream0 + i, seed).reshape(shp)
+        if k.endswith("weight") and len(shp) == 2:
+            fan = shp[0] + shp[1]
+            if "embed" in k:
+                w[k] = ((u - 0.5) * 2 * 0.08).astype(np.float32)
+            else:
+                w[k] = ((u - 0.5) * 2 * gain * np.sqrt(6.0 / fan)).astype(np.float32)
+        elif "layer_norm" in k and k.endswith("weight"):
+            w[k] = (1.0 + 0.2 * (u - 0.5)).astype(np.float32)
+        else:
+            w[k] = (0.1 * (u - 0.5)).astype(np.float32)
+    return w
+
+
+def make_ssp_weights(seed=0, n_verbs=2663, gain=1.6):
+    return _fill(ssp_param_shapes(n_verbs), seed, 500, gain)
+
+
+def make_sinkhorn_weights(seed=0, N=10, gain=1.5):
+    return _fill(sinkhorn_param_shapes(N), seed, 800, gain)
+
+
+def make_ssp_inputs(S, seed=0, n_verbs=2663):
+    """verbs (S,) in [1, n_verbs), roles (S,10): n in [1,10] DISTINCT role ids in 1..25, zero padded (eval_coco.py:150-166)"""
+    verbs = hash_int(S, 1, n_verbs, 900, seed).astype(np.int64)
+    n = hash_int(S, 1, 11, 901, seed)
+    roles = np.zeros((S, 10), dtype=np.int64)
+    for s in range(S):
+        order = np.argsort(hash_u01(25, 902 + s, seed))
+        roles[s, :n[s]] = order[:n[s]] + 1
+    return verbs, roles
+
+
+def make_sinkhorn_inputs(Q, seed=0, N=10):
+    """(Q, N, 2352) region rows [300 + 2048 + 4]: the first n rows are filled (n in [2, N]), the rest is zero (eval_coco.py:178-182)"""
+    n = hash_int(Q, 2, N + 1, 910, seed)
+    x = np.zeros((Q, N, 2352), dtype=np.float32)
+    u = hash_u01(Q * N * 2352, 911, seed).reshape(Q, N, 2352)
+    x[:, :, :300] = (u[:, :, :300] - 0.5) * 2
+    x[:, :, 300:2348] = _sparse_relu(u[:, :, 300:2348])
+    x[:, :, 2348:] = u[:, :, 2348:]
+    for q in range(Q):
+        x[q, n[q]:] = 0
+    return x, n
