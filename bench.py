@@ -154,37 +154,61 @@ def cpu_baseline_xe(weights, sample_B, torch, synth):
 
 # ---------------------------------------------------------------------------------------------- shared pieces
 class Dist:
-    def __init__(self, torch, dist):
-        self.torch, self.dist = torch, dist
+    """backend "nccl" (= RCCL over xGMI): one GPU per rank, collectives on the device.  backend "gloo" is a SELF-TEST of the
+    multi-rank code path on a box with fewer GPUs than ranks: ranks share the visible devices and the collectives are staged
+    through host memory; its numbers are not a measurement of anything."""
+
+    def __init__(self, torch, dist, backend="nccl"):
+        self.torch, self.dist, self.backend = torch, dist, backend
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        index = self.local_rank if backend == "nccl" else self.local_rank % max(1, torch.cuda.device_count())
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                    device_id=torch.device("cuda", self.local_rank))
-        torch.cuda.set_device(self.local_rank)
-        self.dev = torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(index)
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", index))
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+        torch.cuda.set_device(index)
+        self.dev = torch.device("cuda", index)
+
+    def all_reduce_fn(self):
+        """None for RCCL; a host-staged SUM for the gloo self-test (DataParallelStep's all_reduce_fn hook)"""
+        if self.backend == "nccl" or self.world == 1:
+            return None
+
+        def host(t):
+            c = t.detach().cpu()
+            self.dist.all_reduce(c)
+            t.copy_(c)
+        return host
+
+    def gather_ids(self, parallel, w, n_total):
+        if self.backend == "nccl":
+            return parallel.gather_ids(w, n_total)
+        return parallel.gather_ids(w.cpu(), n_total).to(self.dev)
 
     def barrier(self):
+        self.torch.cuda.synchronize(self.dev)
         if self.world > 1:
             self.dist.barrier()
         self.torch.cuda.synchronize(self.dev)
 
     def max_time(self, dt):
         if self.world > 1:
-            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
     def observed_world(self):
-        """what RCCL itself sees: the sum of a ones-vector over the ranks"""
+        """what the collective library itself sees: the sum of a ones-vector over the ranks"""
         if self.world == 1:
             return 1
-        t = self.torch.ones(1, device=self.dev)
+        t = self.torch.ones(1, device=self.dev if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(t)
         return int(t.item())
 
@@ -258,7 +282,7 @@ def decode_bench(args, D, torch, dist, synth):
             else:
                 w, g = m.test(det, ctrl)
             if strong:      # the one exchange of a sharded decode: (B, T) ids of every shard
-                w = parallel.gather_ids(w, c["B"])
+                w = D.gather_ids(parallel, w, c["B"])
             return w
 
     for i in range(args.warmup):
@@ -289,8 +313,8 @@ def decode_bench(args, D, torch, dist, synth):
         "config": {"workload": "%s decode, batch %s, 36 regions x 2048-d, 10 slots, seq_len 20, vocab 10000 (BASELINE configs[%d])" %
                                (name, "100 images split over the ranks (13/12 per GPU at 8)" if strong else "100 images/GPU", 2 if beam > 1 else 1),
                    "beam": beam, "batch_per_gpu": hi - lo, "seq_len": c["T"],
-                   "parallelism": "images sharded, dp%d%s" % (world, ", ids all-gathered (RCCL)" if strong else ", no data-path collective"),
-                   "rccl_world_size_observed": D.observed_world(),
+                   "parallelism": "images sharded, dp%d%s" % (world, ", ids all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo self-test") if strong else ", no data-path collective"),
+                   "rccl_world_size_observed": D.observed_world(), "collective_backend": args.backend,
                    "decode_cache": "prebuilt, weight-only (embedding rows through the x columns of the LSTM1 / gate input weights, "
                                    "240 MB, built once per weight version outside the timed call; all per-image hoisting is inside)"},
         "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic, tsrc, gemm_bytes),
@@ -334,7 +358,7 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
                         torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed)[lo:hi]).contiguous().to(dev),
                         torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed)[lo:hi]).contiguous().to(dev)))
     step = parallel.DataParallelStep(m, opt, forward_fn=lambda d, cp, sq: m((d,), (cp, sq)),
-                                     sample_fn=lambda d, ct: m.sample_rl(d, ct))
+                                     sample_fn=lambda d, ct: m.sample_rl(d, ct), all_reduce_fn=D.all_reduce_fn())
     NS = 5                          # samples per image (BASELINE configs[4]); the reference has no such loop, the caller
     rl_batches = []                 # repeats every image NS times
     if not xe:
@@ -385,7 +409,7 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
                                ("SCST step: greedy baseline (100 images) + sample_rl on 500 rows (5 samples/image) + replayed forward + BPTT "
                                 "backward + Adam(fused=True), rewards = device CIDEr-D vs synthetic references, 10 slots x 36 x 2048 (BASELINE configs[4])"),
                    "batch_per_gpu": hi - lo, "seq_len": c["T"],
-                   "parallelism": "dp%d, RCCL gradient all-reduce in buckets on a side stream, overlapped with the weight-gradient GEMMs" % world,
+                   "parallelism": "dp%d, %s gradient all-reduce in buckets on a side stream, overlapped with the weight-gradient GEMMs" % (world, "RCCL" if args.backend == "nccl" else "gloo (self-test, host-staged)"),
                    "rccl_world_size_observed": D.observed_world()},
         "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, gemm_bytes=gemm_bytes),
     }
@@ -406,6 +430,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the XE-step leg of the default line")
     ap.add_argument("--cpu-sample", type=int, default=12)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL, one GPU per rank (the measurement); gloo = self-test of the multi-rank path on fewer GPUs than ranks")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -414,7 +440,7 @@ def main():
     import torch
     import torch.distributed as dist
     from vsrcap import synth
-    D = Dist(torch, dist)
+    D = Dist(torch, dist, args.backend)
     if args.gpus != D.world and D.rank == 0:
         print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, D.world, D.world), file=sys.stderr)
 
