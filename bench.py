@@ -239,6 +239,13 @@ def roofline_block(dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic=No
                 "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1), "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt,
                 "mfma_tflops_for_reference": achieved, "mfma_frac_of_dense_bf16_peak": achieved / PEAK_BF16_MFMA_TFLOPS}
     peak = PEAK_F32_MFMA_TFLOPS
+    if dtype == "f32x3":
+        r = {"bound": "mfma", "kernel": "gemm_nt_f32x3_kernel (fp32 operands split into 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per product)",
+             "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS / 6.0, "unit": "TFLOP/s (fp32-equivalent)", "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0),
+             "traffic": None, "launches": gemm_seen, "launches_timed": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
+             "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt, "algorithmic_flops_per_launch": gemm_flops / max(gemm_n, 1),
+             "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+        return r
     r = {"bound": "mfma",
          "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32; problems of <= 48 rows: gemm_nt_f32_r16_kernel, v_mfma_f32_16x16x4_f32)",
          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
@@ -425,10 +432,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="beam5", choices=["beam5", "beam5idx", "greedy", "xe", "scst"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"],
                     help="f32 = parity mode (headline); bf16 = throughput mode (bf16 operands, fp32 accumulate, fp32 master weights)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the XE-step leg of the default line")
+    ap.add_argument("--no-alt", action="store_true", help="skip the f32x3 / bf16 legs of the default line")
     ap.add_argument("--cpu-sample", type=int, default=12)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (the measurement); gloo = self-test of the multi-rank path on fewer GPUs than ranks")
@@ -457,6 +465,17 @@ def main():
             xe_line, _ = train_bench(xa, D, torch, dist, synth, max(5, args.steps // 2), 2)
             line["secondary"] = {k: xe_line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                                          "scaling", "dtype", "config", "roofline")}
+        if args.workload == "beam5" and args.dtype == "f32" and not args.no_alt:
+            # the same workload in the two optional GEMM flavours, for the record (never the headline `value`):
+            #   f32x3 = fp32-accurate products on the bf16 matrix cores (same fixtures, same bounds: tests/test_gpu_f32x3.py)
+            #   bf16  = throughput mode (tests/test_gpu_bf16.py states its deviation)
+            line["alt_modes"] = {}
+            for dt in ("f32x3", "bf16"):
+                aa = argparse.Namespace(**vars(args))
+                aa.dtype = dt
+                aa.steps, aa.warmup = max(5, args.steps // 2), 2
+                al, _, _ = decode_bench(aa, D, torch, dist, synth)
+                line["alt_modes"][dt] = {k: al[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline")}
         if D.rank == 0 and D.world == 1 and not args.no_cpu and args.workload != "beam5idx":
             line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam, torch, synth)
     if D.rank == 0:

@@ -110,6 +110,13 @@ int vsr_build_decode_cache(vsr_handle* h, float* buffer, size_t n_floats, void* 
 size_t vsr_bf16_weight_bytes(const vsr_handle* h);
 int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream);
 
+/* fp32 GEMM flavour of a handle.  0 (default): exact k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32 - the mode the parity
+ * fixtures were generated against.  1 ("f32x3"): every fp32 operand is split into three bf16 terms on its way into LDS
+ * (x = hi + mid + lo exactly) and a product is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped cross terms are
+ * below one fp32 rounding of the product.  Operands stay fp32 in memory (no copies).  Not bit-identical to mode 0; admitted by
+ * the same parity suite (tests/test_gpu_f32x3.py). */
+int vsr_set_gemm_mode(vsr_handle* h, int32_t mode);
+
 /* ---- workspace ------------------------------------------------------------------------------------ */
 /* bytes needed for B images with L slots of R regions, R0 pooled regions, decoding with up to `beam`
  * hypotheses per image (1 for greedy / sampling / teacher forcing). */

@@ -12,6 +12,7 @@
 #include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
 #include "gemm_bf16x3.h"
 #include "gemm_dma_variant.h"
+#include "../vsr-guided-cic_amd/csrc/gemm_f32x3.h"
 
 using namespace vsr;
 
@@ -44,6 +45,7 @@ struct Builder {
         if (tm == 2242) { bm = 256; bn = 128; }
         if (tm == 2142) { bm = 256; bn = 64; }
         if (tm == 2224) { bm = 128; bn = 256; }
+        if (tm == 3300) { bm = 128; bn = 256; }                                      // f32x3 kernel
         if (tm > 1600 && tm <= 1608) { bm = 16 * (tm - 1600); bn = 64 * tn; }      // rows-16 kernel: tm = 1600 + TM, tn = TN
         int ns = gemm_plan(a, slots, min_iters, bm, bn);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
@@ -54,7 +56,8 @@ struct Builder {
         dim3 g(((a.G + 7) / 8) * 8), b(256);
 #define R16(TM_) else if (tm == 1600 + TM_ && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 2>), g, dim3(512), 0, st, a); \
                  else if (tm == 1600 + TM_ && tn == 4) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 4>), g, dim3(512), 0, st, a);
-        if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
+        if (tm == 3300) hipLaunchKernelGGL((gemm_nt_f32x3_kernel<2, 4, 2, 2>), g, dim3(512), 0, st, a);
+        else if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
         R16(1) R16(2) R16(4) R16(7) R16(8)
         else if (tm == 322) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2>), g, b, 0, st, a);
         else if (tm == 321) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 1, 2, 2>), g, b, 0, st, a);

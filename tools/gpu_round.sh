@@ -19,22 +19,25 @@ scst)
   timeout 300 python bench.py --workload scst --no-cpu > $OUT/bench_scst.json 2> $OUT/bench_scst.err; cat $OUT/bench_scst.json ;;
 bf16)
   for w in beam5 greedy xe; do timeout 300 python bench.py --workload $w --dtype bf16 --no-cpu --no-secondary > $OUT/bench_${w}_bf16.json 2> $OUT/bench_${w}_bf16.err; cat $OUT/bench_${w}_bf16.json; done
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_beam5_bf16 -- python3 $GRAFT_REPO_ROOT/bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu --no-secondary > $GRAFT_REPO_ROOT/$OUT/stats_beam5_bf16.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_beam5_bf16 -- python3 $GRAFT_REPO_ROOT/bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu --no-secondary --no-alt > $GRAFT_REPO_ROOT/$OUT/stats_beam5_bf16.log 2>&1)
   for f in $(find $OUT/stats_beam5_bf16 -name "*kernel_stats.csv"); do head -12 $f; done
   for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc16_$c -- python3 $GRAFT_REPO_ROOT/bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu --no-secondary > $GRAFT_REPO_ROOT/$OUT/pmc16_$c.log 2>&1)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc16_$c -- python3 $GRAFT_REPO_ROOT/bench.py --dtype bf16 --steps 2 --warmup 1 --no-cpu --no-secondary --no-alt > $GRAFT_REPO_ROOT/$OUT/pmc16_$c.log 2>&1)
   done
   python tools/hbm_traffic.py $OUT/pmc16_FETCH_SIZE $OUT/pmc16_WRITE_SIZE $OUT/gemm_bf16_hbm_traffic.json gemm_nt_bf16w
   find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
+x3)
+  VSR_COMPUTE_DTYPE=f32x3 timeout 1500 python -m pytest tests -m gpu -q -rA --deselect tests/test_gpu_bf16.py > $OUT/pytest_f32x3.log 2>&1; echo "pytest(f32x3) rc=$?" >> $OUT/pytest_f32x3.log; tail -5 $OUT/pytest_f32x3.log
+  for w in beam5 greedy xe; do timeout 300 python bench.py --workload $w --dtype f32x3 --no-cpu --no-secondary --no-alt > $OUT/bench_${w}_f32x3.json 2> $OUT/bench_${w}_f32x3.err; cat $OUT/bench_${w}_f32x3.json; done ;;
 stats)
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_beam5 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-secondary > $GRAFT_REPO_ROOT/$OUT/stats_beam5.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_beam5 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-secondary --no-alt > $GRAFT_REPO_ROOT/$OUT/stats_beam5.log 2>&1)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_xe -- python3 $GRAFT_REPO_ROOT/bench.py --workload xe --steps 5 --warmup 2 --no-cpu > $GRAFT_REPO_ROOT/$OUT/stats_xe.log 2>&1)
   find $OUT -name "*kernel_stats.csv" | head; for f in $(find $OUT -name "*kernel_stats.csv"); do echo $f; head -25 $f; done
   # keep only the stats (traces are large)
   find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary > $GRAFT_REPO_ROOT/$OUT/pmc_$c.log 2>&1)
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --no-alt > $GRAFT_REPO_ROOT/$OUT/pmc_$c.log 2>&1)
   done
   python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/gemm_hbm_traffic.json gemm_
   python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/attend_hbm_traffic.json k_attend

@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "vsrcap.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "gemm_f32.h"), os.path.join(HERE, "csrc", "gemm_bf16.h"), os.path.join(HERE, "csrc", "kernels.h"),
+DEPS = [SRC, os.path.join(HERE, "csrc", "gemm_f32.h"), os.path.join(HERE, "csrc", "gemm_bf16.h"), os.path.join(HERE, "csrc", "gemm_f32x3.h"), os.path.join(HERE, "csrc", "ssp_kernels.h"), os.path.join(HERE, "csrc", "ssp.inc.h"), os.path.join(HERE, "csrc", "kernels.h"),
         os.path.join(HERE, "csrc", "train_kernels.h"), os.path.join(HERE, "csrc", "train.inc.h"),
         os.path.join(HERE, "csrc", "cider.inc.h"),
         os.path.join(os.path.dirname(HERE), "include", "vsrcap.h")]

@@ -1,0 +1,305 @@
+// "f32x3": fp32-accurate stream-K "NT" GEMM on the bf16 matrix cores.  OPTIONAL mode (model.set_compute_dtype('f32x3'),
+// bench.py --dtype f32x3); the default fp32 path stays the exact k-ordered fma chain of gemm_f32.h.
+//
+// Both operands are fp32 in memory (no copies).  On its way into LDS every element x is split into three bf16 terms
+//     hi = bf16(x),  mid = bf16(x - hi),  lo = bf16(x - hi - mid)         (x = hi + mid + lo exactly: 3 x 8 = 24 mantissa bits)
+// and a product a.b is accumulated in fp32 as  hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid  (six
+// v_mfma_f32_32x32x16_bf16); the dropped terms mid.lo, lo.mid, lo.lo are <= 2^-23 of the product - the size of the ONE
+// rounding the fp32 fma chain commits per product.  Round 1 measured this split against fp64 at K = 1000: rms 5.0e-7 vs
+// 7.5e-7 for the fp32 chain.  It is NOT bit-identical to the chain (a different summation order, like any other fp32 GEMM):
+// the parity suite is what admits it (tests/test_gpu_f32x3.py: every token fixture, the 1e-4 loss bound, the gradient bounds).
+//
+// Why: six bf16 MFMAs cost 6/16 of the fp32 MFMA time, so the kernel can afford the tile that halves the bytes per flop
+// (128 x 256 x 32, 43 flop per loaded byte against 21 for the fp32 kernel's 128 x 64) - the fp32 kernel is pinned at 0.65 of
+// its MFMA peak by the chip.  Structure = gemm_bf16.h: 8 waves (2 x 4, 64 x 64 per wave), whole-line
+// loads, loads issued two tiles ahead, LDS-staged epilogue.  LDS: three bf16 planes of (128 + 256) rows x 32, rows unpadded
+// (64 bytes), 16-byte chunk c of row r at position c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 for the 32x32x16 operand
+// map), double buffered: 147 KB.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_bf16.h"
+
+namespace vsr {
+
+#ifndef X3_EXP
+#define X3_EXP 0      // diagnostics (tools/gemm_bench.hip): 1 no split, 2 no global loads in the loop, 3 one MFMA term of six
+#endif
+constexpr int X3_BK = 32;
+constexpr int X3_ROW = 32;                               // bf16 elements per LDS row (64 bytes, unpadded, XOR-swizzled chunks)
+
+// x -> (hi, mid, lo) for two values at once: three packed bf16 pairs
+__device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = pack_bf16(a, b);
+    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
+    const float ar = a - ah, br = b - bh;                // exact (Sterbenz-like: hi is a's leading 8 bits)
+    mid = pack_bf16(ar, br);
+    const float am = __uint_as_float(mid << 16), bm = __uint_as_float(mid & 0xffff0000u);
+    lo = pack_bf16(ar - am, br - bm);
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN)
+void gemm_nt_f32x3_kernel(const GemmArgs args) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int BK = X3_BK;
+    constexpr int RP = NT / 8;                            // rows per load pass: 8 lanes x float4 cover a row's k-tile (one 128-byte line)
+    constexpr int LA = BM / RP, LB = BN / RP;
+    static_assert(BM % RP == 0 && BN % RP == 0, "tile shape");
+    constexpr int PLANE = (BM + BN) * X3_ROW;             // bf16 elements per plane
+    constexpr int BUF = 3 * PLANE;                        // hi | mid | lo
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];           // 147 KB of the CU's 160 KB: one workgroup per CU
+
+    const int G = args.G;
+    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
+    if (g >= G) return;
+    const int it0 = gemm_range_begin(g, args.total_iters, G);
+    const int it1 = gemm_range_begin(g + 1, args.total_iters, G);
+    if (it0 >= it1) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, hh = lane >> 5;
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;        // this thread's row (per pass) and its 4 fp32 of the k-tile
+
+    float4 ra[LA], rb[LB];
+    const float* pa[LA];
+    const float* pb[LB];
+    int l_prob = 0, l_tile = 0, l_tile_left = 0;
+    int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;
+    auto open_segment = [&](int s, int first_tile) __attribute__((always_inline)) {
+        const GemmProb& P = args.p[l_prob];
+        const GemmSeg& S = P.seg[s];
+        const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
+        l_seg = s;
+        l_K = S.K;
+        l_k = first_tile * BK;
+        l_seg_left = (S.K + BK - 1) / BK - first_tile;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            int m = m0 + lrow + RP * i;
+            m = m < P.M ? m : P.M - 1;
+            const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
+            pa[i] = S.A + row * S.lda + lk;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            int n = n0 + lrow + RP * i;
+            n = n < P.N ? n : P.N - 1;
+            pb[i] = S.W + (long long)n * S.ldw + lk;
+        }
+    };
+    auto open_tile = [&](int prob, int tile, int kt) __attribute__((always_inline)) {
+        l_prob = prob;
+        l_tile = tile;
+        const GemmProb& P = args.p[prob];
+        l_tile_left = P.ktiles - kt;
+        int s = 0;
+        while (s < P.nseg - 1 && kt >= (P.seg[s].K + BK - 1) / BK) { kt -= (P.seg[s].K + BK - 1) / BK; ++s; }
+        open_segment(s, kt);
+    };
+    int ko = 0;
+    bool tail = false;
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (l_tile_left == 0) {
+            if (l_tile + 1 < args.p[l_prob].tiles_m * args.p[l_prob].tiles_n) open_tile(l_prob, l_tile + 1, 0);
+            else open_tile(l_prob + 1, 0, 0);
+        } else if (l_seg_left == 0) {
+            open_segment(l_seg + 1, 0);
+        }
+        tail = !(l_k + lk < l_K);                          // K is a multiple of 4
+        ko = tail ? 0 : l_k;
+        l_k += BK;
+        --l_seg_left;
+        --l_tile_left;
+    };
+    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = *reinterpret_cast<const float4*>(pa[i] + ko); };
+    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = *reinterpret_cast<const float4*>(pb[i] + ko); };
+    bool stail = false;
+    // row R of the tile (A rows first, then W rows), this thread's 4 k's: 8 bytes per plane at chunk (lk / 8) ^ ((R >> 2) & 3)
+    auto put = [&](uint16_t* buf, int R, float4 v) __attribute__((always_inline)) {
+        if (stail) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t h0, m0, l0, h1, m1, l1;
+#if X3_EXP == 1
+        h0 = __float_as_uint(v.x); m0 = __float_as_uint(v.y); l0 = 0; h1 = __float_as_uint(v.z); m1 = __float_as_uint(v.w); l1 = 0;
+#else
+        split3(v.x, v.y, h0, m0, l0);
+        split3(v.z, v.w, h1, m1, l1);
+#endif
+        const int pos = R * X3_ROW + 8 * ((lk >> 3) ^ ((R >> 2) & 3)) + (lk & 4);
+        *reinterpret_cast<uint2*>(buf + pos) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(buf + PLANE + pos) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(buf + 2 * PLANE + pos) = make_uint2(l0, l1);
+    };
+    auto store_tile = [&](int b) __attribute__((always_inline)) {
+        uint16_t* buf = smem + b * BUF;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) put(buf, lrow + RP * i, ra[i]);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) put(buf, BM + lrow + RP * i, rb[i]);
+    };
+
+    int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0;
+    bool c_last = false;
+    auto decode = [&](int it) __attribute__((always_inline)) {
+        int p = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i < args.nprob && it >= args.p[i].it_begin) p = i;
+        const GemmProb& P = args.p[p];
+        const int local = it - P.it_begin;
+        c_prob = p;
+        c_tile = local / P.ktiles;
+        const int kt = local - c_tile * P.ktiles;
+        const int tile_base = it - kt;
+        const int g_first = (int)((((long long)tile_base + 1) * G - 1) / args.total_iters);
+        c_piece = g - g_first;
+        const int rem = P.ktiles - kt;
+        c_left = rem < it1 - it ? rem : it1 - it;
+        c_last = (c_left == rem);
+        return kt;
+    };
+
+    constexpr int ST_LD = BN + 4;
+    static_assert(32 * ST_LD * 4 <= BUF * 2, "staging band must fit one k buffer");
+    auto flush = [&](const f32x16 (&acc)[TM][TN], float* stage) __attribute__((always_inline)) {
+        const GemmProb& P = args.p[c_prob];
+        const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
+        float* C = P.C + (long long)c_piece * P.slab_stride;
+        const int extra = c_last ? args.nslab - 1 - c_piece : 0;
+        const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
+        constexpr int TPR = BN / 4;
+        constexpr int RPP = NT / TPR;
+        const int c4 = (tid % TPR) * 4;
+        const int n = n0 + c4;
+#pragma unroll
+        for (int band = 0; band < BM / 32; ++band) {
+#pragma unroll
+            for (int ti = 0; ti < TM; ++ti)
+                if (wm * TM + ti == band) {
+#pragma unroll
+                    for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 32 / RPP; ++i) {
+                const int sr = tid / TPR + RPP * i;
+                const int m = m0 + band * 32 + sr;
+                if (m < P.M && n < P.N) {
+                    const float4 v = *reinterpret_cast<const float4*>(stage + sr * ST_LD + c4);
+                    float* dst = C + (long long)m * P.ldc + n;
+                    if (vec_ok && n + 3 < P.N) {
+                        *reinterpret_cast<float4*>(dst) = v;
+                        for (int x = 1; x <= extra; ++x)
+                            *reinterpret_cast<float4*>(dst + (long long)x * P.slab_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < P.N) {
+                                dst[q] = vv[q];
+                                for (int x = 1; x <= extra; ++x) dst[(long long)x * P.slab_stride + q] = 0.f;
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    };
+
+    {
+        const int kt = decode(it0);
+        open_tile(c_prob, c_tile, kt);
+    }
+    advance();
+#pragma unroll
+    for (int i = 0; i < LA; ++i) load_a(i);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) load_b(i);
+    stail = tail;
+    store_tile(0);
+    if (it0 + 1 < it1) {
+        advance();
+#pragma unroll
+        for (int i = 0; i < LA; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) load_b(i);
+        stail = tail;
+    }
+    __syncthreads();
+    int cur = 0;
+    const int swz = (r >> 2) & 3;                          // rows 32 t + r of every subtile share it
+    for (int it = it0; it < it1;) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int n_it = c_left;
+        for (int j_it = 0; j_it < n_it; ++j_it, ++it) {
+            const bool more = it + 1 < it1, more2 = it + 2 < it1;
+            if (more) store_tile(cur ^ 1);                 // tile it + 1: split into the three planes of the idle buffer
+            if (more2) {
+                advance();
+                if (X3_EXP != 2) {
+#pragma unroll
+                    for (int i = 0; i < LA; ++i) load_a(i);
+#pragma unroll
+                    for (int i = 0; i < LB; ++i) load_b(i);
+                }
+            }
+            const uint16_t* base = smem + cur * BUF;
+            const uint16_t* a_row = base + (wm * (32 * TM) + r) * X3_ROW;
+            const uint16_t* b_row = base + (BM + wn * (32 * TN) + r) * X3_ROW;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int ch = 8 * ((2 * kk + hh) ^ swz);  // lane (r, hh) reads k = 8 hh + 16 kk .. +7: chunk 2 kk + hh, swizzled
+                bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8_t*>(a_row + i * 32 * X3_ROW + ch);
+                    am[i] = *reinterpret_cast<const bf16x8_t*>(a_row + PLANE + i * 32 * X3_ROW + ch);
+                    al[i] = *reinterpret_cast<const bf16x8_t*>(a_row + 2 * PLANE + i * 32 * X3_ROW + ch);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const bf16x8_t*>(b_row + j * 32 * X3_ROW + ch);
+                    bm[j] = *reinterpret_cast<const bf16x8_t*>(b_row + PLANE + j * 32 * X3_ROW + ch);
+                    bl[j] = *reinterpret_cast<const bf16x8_t*>(b_row + 2 * PLANE + j * 32 * X3_ROW + ch);
+                }
+                // smallest terms first, the leading product last
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (X3_EXP != 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (more2) stail = tail;
+            if (more) {
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        flush(acc, reinterpret_cast<float*>(smem + (cur ^ 1) * BUF));
+        if (it < it1) decode(it);
+    }
+}
+
+constexpr size_t X3_LDS_BYTES = (size_t)2 * 3 * (128 + 256) * X3_ROW * sizeof(uint16_t);
+
+}  // namespace vsr

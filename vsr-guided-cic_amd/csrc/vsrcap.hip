@@ -25,6 +25,7 @@
 
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
+#include "gemm_f32x3.h"
 #include "kernels.h"
 #include "train_kernels.h"
 
@@ -86,6 +87,7 @@ struct vsr_handle {
     TrainCtx* tc = nullptr;
     // bf16 throughput mode (gemm_bf16.h): off unless vsr_refresh_bf16_weights() has been given a buffer
     bool bf16_on = false;
+    bool x3_on = false;               // fp32 products through three bf16 terms per operand (gemm_f32x3.h); fp32 operands, no copies
     std::vector<Bf16Range> b16;        // weights (refresh) + the training pass's transposed operands (carve_train)
     size_t b16_weights = 0;            // entries of b16 that belong to the weights
     int gemm_slots_bf16 = 256;         // ONE 8-wave workgroup per CU (108 KB of LDS: two 128+256-row x 64-k bf16 buffers)
@@ -239,6 +241,19 @@ struct GemmBuilder {
             }
         }
         big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM >= 1024 ? 2 : maxM > 192 ? 1 : 0);
+        if (h->x3_on) {
+            bool ok = true;
+            for (int i = 0; i < a.nprob && ok; ++i)
+                for (int sg = 0; sg < a.p[i].nseg && ok; ++sg) {
+                    const GemmSeg& S = a.p[i].seg[sg];
+                    ok = (S.K % 4 == 0) && (S.ldw % 4 == 0) && (S.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.W) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(S.A) & 15) == 0);
+                }
+            if (ok) {
+                big = 33;
+                return gemm_plan(a, h->gemm_slots_bf16, 4, 128, 256, X3_BK);
+            }
+        }
         if (h->gemm_tile == 0 && maxM <= h->gemm_r16_max) {
             // short problems: every row of an m-tile in one workgroup, rows in units of 16 (M = 100 -> 112, not 128)
             const int tiles = (maxM + 127) / 128;
@@ -256,10 +271,11 @@ struct GemmBuilder {
 };
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
-    dim3 grid(((a.G + 7) / 8) * 8), block(big == 16 || big == 32 ? 512 : 256);
+    dim3 grid(((a.G + 7) / 8) * 8), block(big == 16 || big == 32 || big == 33 ? 512 : 256);
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
-    if (big == 32) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<2, 4, 2, 2>), grid, block, 0, s, a);
+    if (big == 33) hipLaunchKernelGGL((gemm_nt_f32x3_kernel<2, 4, 2, 2>), grid, block, 0, s, a);
+    else if (big == 32) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<2, 4, 2, 2>), grid, block, 0, s, a);
     else if (big == 16) {
         switch (r16_tm) {
             case 1: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<1, 2>), grid, block, 0, s, a); break;
@@ -481,6 +497,16 @@ extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t byte
     LAUNCHCHK();
     if (!h->bf16_on) h->xproj = nullptr;
     h->bf16_on = true;
+    return 0;
+}
+
+// fp32 GEMM flavour: 0 = exact k-ordered fma chain (v_mfma_f32_32x32x2_f32; the default and the mode every fixture was made for),
+// 1 = "f32x3": each fp32 operand split into three bf16 terms, six bf16 MFMAs per product, fp32 accumulation (gemm_f32x3.h)
+extern "C" int vsr_set_gemm_mode(vsr_handle* h, int32_t mode) {
+    if (!h) return fail("vsr_set_gemm_mode: null handle");
+    if (mode != 0 && mode != 1) return fail("vsr_set_gemm_mode: mode %d not in {0, 1}", mode);
+    if (h->x3_on != (mode == 1)) h->xproj = nullptr;       // the decode cache is rebuilt in the new flavour
+    h->x3_on = mode == 1;
     return 0;
 }
 

@@ -69,14 +69,17 @@ class ControllableCaptioningModel(CaptioningModel):
         # set force_prepare = True when inputs / weights are rewritten in ways that do not bump _version
         # (t.data.copy_, DLPack / custom-kernel writes, p.data edits), or call invalidate_cache() after such a write
         self.force_prepare = False
-        self.compute_dtype = 'f32'
+        # VSR_COMPUTE_DTYPE lets a whole test run (or an unchanged reference script) select the GEMM flavour without code changes
+        self.compute_dtype = os.environ.get('VSR_COMPUTE_DTYPE', 'f32')
 
     def set_compute_dtype(self, dtype):
         """'f32' (default): the reference's precision, the mode token parity and the 1e-4 loss bound hold in.
+        'f32x3': fp32-accurate products on the bf16 matrix cores (each fp32 operand split into three bf16 terms, six MFMAs per
+        product, fp32 accumulation; csrc/gemm_f32x3.h) - same operands, same fixtures, a different summation order.
         'bf16': throughput mode - matrix products take bf16 operands with fp32 accumulation (v_mfma_f32_32x32x16_bf16);
         parameters, optimizer state, states and reductions stay fp32.  Not a parity mode."""
-        if dtype not in ('f32', 'bf16'):
-            raise ValueError("compute dtype must be 'f32' or 'bf16'")
+        if dtype not in ('f32', 'bf16', 'f32x3'):
+            raise ValueError("compute dtype must be 'f32', 'f32x3' or 'bf16'")
         self.compute_dtype = dtype
         return self
 
@@ -119,6 +122,7 @@ class ControllableCaptioningModel(CaptioningModel):
             raise RuntimeError("model parameters are on %s but the inputs are on %s" % (pdev, device))
         self._eng.bind(params)
         self._eng.set_bf16(pdev, self._weights_version(), self.compute_dtype == 'bf16')
+        self._eng.set_gemm_mode(self.compute_dtype == 'f32x3')
         # inference keeps a weight-only cache (embedding projection); while training the weights move every step
         self._eng.decode_cache(pdev, self._weights_version(), enable=not self.training)
         return self._eng

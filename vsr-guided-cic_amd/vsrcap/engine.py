@@ -123,6 +123,15 @@ class Engine:
         self._verb_dev = (rp, fl)
         _lib.check(self.lib.vsr_set_verb_table(self.h, _ptr(rp), _ptr(fl), n))
 
+    def set_gemm_mode(self, x3):
+        """False: exact fp32 fma chain (default); True: "f32x3" (three bf16 terms per fp32 operand, include/vsrcap.h)"""
+        x3 = bool(x3)
+        if x3 != getattr(self, "_x3", False):
+            _lib.check(self.lib.vsr_set_gemm_mode(self.h, 1 if x3 else 0))
+            self._x3 = x3
+            self._cache_key = None
+            self._prep_key = None
+
     # ------------------------------------------------------------------ bf16 throughput mode
     @_on_device
     def set_bf16(self, device, weights_version, enable):
