@@ -241,7 +241,7 @@ struct GemmBuilder {
             }
         }
         big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM >= 1024 ? 2 : maxM > 192 ? 1 : 0);
-        if (h->x3_on) {
+        if (h->x3_on && maxM > 192) {        // below that the 128 x 256 tile has too few tiles (measured slower than the exact kernels at M = 100)
             bool ok = true;
             for (int i = 0; i < a.nprob && ok; ++i)
                 for (int sg = 0; sg < a.p[i].nseg && ok; ++sg) {
