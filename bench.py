@@ -247,7 +247,7 @@ def roofline_block(dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic=No
              "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
         return r
     r = {"bound": "mfma",
-         "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32; problems of <= 48 rows: gemm_nt_f32_r16_kernel, v_mfma_f32_16x16x4_f32)",
+         "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32; problems of <= 80 rows: gemm_nt_f32_r16_kernel, v_mfma_f32_16x16x4_f32)",
          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
          "launches": gemm_seen, "launches_timed": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
          "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt,
@@ -438,10 +438,13 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the XE-step leg of the default line")
     ap.add_argument("--no-alt", action="store_true", help="skip the f32x3 / bf16 legs of the default line")
     ap.add_argument("--cpu-sample", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=0, help="images per batch instead of 100 (experiments only: not the BASELINE workload)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (the measurement); gloo = self-test of the multi-rank path on fewer GPUs than ranks")
     args = ap.parse_args()
 
+    if args.batch > 0:
+        CFG["B"] = args.batch
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 

@@ -110,9 +110,9 @@ struct vsr_handle {
     // one MI355X: at M = 100 it is level with the 64x64 kernel inside a GEMM (61.5 vs 60.6 TF/s) but its tiles are cut into
     // 7-8 stream-K pieces instead of 4-6, and the consumers' extra slab reads cost more than its 11 %-instead-of-28 %
     // padding saves (greedy 459 k vs 481 k tokens/s, XE step 6.8 k vs 7.4 k samples/s).  Below 64 rows (a data-parallel
-    // shard of 12-13 images, small eval batches) the 64-row tile is mostly padding and the rows-16 kernel wins
-    // (M = 13: 19.5 vs 13.2 TF/s over the four step GEMMs).
-    int gemm_r16_max = 48;
+    // shard of 12-13 images and its 65 beam rows, small eval batches) the 64-row tiles are mostly padding and the rows-16 kernel wins
+    // (M = 13: 19.5 vs 13.2 TF/s over the four step GEMMs; beam-5 over a 13-image shard, M = 65: 3.48 vs 3.81 ms per call).
+    int gemm_r16_max = 80;
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
     int gemm_tile = 0;           // 0 = by M; VSR_GEMM_TILE=64 | 12864 | 128 forces 64x64 / 128x64 / 128x128
     Ctx c;
