@@ -105,6 +105,7 @@ struct vsr_handle {
     int gemm_slots = 1024;       // resident 64x64 GEMM workgroups to fill: 256 CUs x 4 (36.9 KB LDS each)
     int gemm_slots_small = 768;  // 64x64 tiles (M <= 192): 3 per CU measured best (greedy 473 k vs 461 k tokens/s at 4 per CU)
     int gemm_min_iters = 8;
+    int gemm_x3_min_rows = 193;  // f32x3 flavour: launches with fewer rows stay on the exact kernels (VSR_X3_MIN_ROWS)
     int gemm_slots_r16 = 256;    // rows-16 kernel: ONE 8-wave workgroup per CU (two waves per SIMD)
     // Problems with at most this many rows take the rows-16 kernel (VSR_GEMM_R16_MAX=0 disables it).  Measured end to end on
     // one MI355X: at M = 100 it is level with the 64x64 kernel inside a GEMM (61.5 vs 60.6 TF/s) but its tiles are cut into
@@ -241,7 +242,7 @@ struct GemmBuilder {
             }
         }
         big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM >= 1024 ? 2 : maxM > 192 ? 1 : 0);
-        if (h->x3_on && maxM > 192) {        // below that the 128 x 256 tile has too few tiles (measured slower than the exact kernels at M = 100)
+        if (h->x3_on && maxM >= h->gemm_x3_min_rows) {        // below that the 128 x 256 tile has too few tiles (measured slower than the exact kernels at M = 100)
             bool ok = true;
             for (int i = 0; i < a.nprob && ok; ++i)
                 for (int sg = 0; sg < a.p[i].nseg && ok; ++sg) {
@@ -327,6 +328,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
         h->gemm_slots_r16 = prop.multiProcessorCount;
         h->gemm_slots_bf16 = prop.multiProcessorCount;
     }
+    if (const char* e = getenv("VSR_X3_MIN_ROWS")) h->gemm_x3_min_rows = atoi(e);
     if (const char* e = getenv("VSR_GEMM_SLOTS_BF16")) h->gemm_slots_bf16 = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_R16")) h->gemm_slots_r16 = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_R16_MAX")) h->gemm_r16_max = atoi(e);
