@@ -32,8 +32,6 @@ extern "C" void vsr_ssp_destroy(vsr_ssp* e) { delete e; }
 extern "C" int vsr_ssp_bind(vsr_ssp* e, const vsr_ssp_weights* w, const vsr_sinkhorn_weights* sw) {
     if (!e) return fail("vsr_ssp_bind: null handle");
     if (w) {
-        const float* const* p = reinterpret_cast<const float* const*>(&w->sr_embed);
-        (void)p;
         if (!w->sr_embed || !w->v_embed || !w->fc_w || !w->exp_w || w->n_verbs <= 0) return fail("vsr_ssp_bind: incomplete S-SSP weights");
         e->w = *w;
         e->has_ssp = true;

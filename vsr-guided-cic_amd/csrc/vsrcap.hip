@@ -445,9 +445,7 @@ extern "C" int vsr_build_decode_cache(vsr_handle* h, float* buf, size_t n_floats
 
 // ---- bf16 throughput mode: bf16 copies of the 14 weight matrices the GEMMs multiply by (fp32 stays the master copy)
 static const int B16_NW = 14;
-static void b16_weight_list(const vsr_handle* h, const float* (&ptr)[B16_NW], size_t (&n)[B16_NW]) {
-    const vsr_dims& d = h->d;
-    const vsr_weights& w = h->w;
+static void b16_weight_list(const vsr_dims& d, const vsr_weights& w, const float* (&ptr)[B16_NW], size_t (&n)[B16_NW]) {
     const size_t H = d.rnn_size, A = d.att_size, D = d.det_feat_size, E = d.input_encoding_size, V = d.vocab_size;
     const size_t in1 = (d.h2_first_lstm ? H : 0) + D + E, in2 = H + D + (d.img_second_lstm ? D : 0);
     const float* p[B16_NW] = {w.W1_is_weight, w.W1_hs_weight, w.att_va_weight, w.att_ha_weight, w.att_sa_weight, w.lstm1_weight_ih,
@@ -459,10 +457,9 @@ static void b16_weight_list(const vsr_handle* h, const float* (&ptr)[B16_NW], si
 extern "C" size_t vsr_bf16_weight_bytes(const vsr_handle* h) {
     if (!h) return 0;
     const float* p[B16_NW]; size_t n[B16_NW];
-    vsr_handle tmp_dims;                       // only the sizes are needed (pointers may be unbound)
-    tmp_dims.d = h->d;
-    memset(&tmp_dims.w, 0, sizeof(tmp_dims.w));
-    b16_weight_list(&tmp_dims, p, n);
+    vsr_weights none;                          // only the sizes are needed (the weights may be unbound)
+    memset(&none, 0, sizeof(none));
+    b16_weight_list(h->d, none, p, n);
     size_t tot = 0;
     for (int i = 0; i < B16_NW; ++i) tot += ((n[i] + 7) & ~size_t(7)) * sizeof(uint16_t);
     return tot + 256;
@@ -485,7 +482,7 @@ extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t byte
     if (reinterpret_cast<uintptr_t>(buffer) & 15) return fail("vsr_refresh_bf16_weights: buffer must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const float* p[B16_NW]; size_t n[B16_NW];
-    b16_weight_list(h, p, n);
+    b16_weight_list(h->d, h->w, p, n);
     std::vector<Bf16Range> keep(h->b16.begin() + h->b16_weights, h->b16.end());   // training operands registered by carve_train
     h->b16.resize(0);
     uint16_t* out = reinterpret_cast<uint16_t*>(buffer);

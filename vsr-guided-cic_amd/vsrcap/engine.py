@@ -97,7 +97,8 @@ class Engine:
         buffer, p.data edits of the weights) are invisible to it - call this after such a write."""
         self._prep_key = None
         self._cache_key = None
-        self._bf16_key = None if getattr(self, "_bf16_key", None) is None else ()
+        if getattr(self, "_bf16_key", None) is not None:
+            self._bf16_key = ("stale",)          # bf16 mode stays on; the copies are rebuilt by the next set_bf16()
 
     def raise_on_bad_ids(self, device, who):
         if not self.check_ids:

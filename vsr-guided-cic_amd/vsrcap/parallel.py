@@ -138,6 +138,15 @@ class DataParallelStep:
             self.n_buckets = 1
             self.comm_stream = None
 
+    def close(self):
+        """Give the model back to plain autograd: while a DataParallelStep owns it, vsr_train_backward writes the gradients
+        into this step's flat buffer (eng.grad_sink) and the autograd Function returns no tensors - a loss.backward() outside
+        the step object would therefore leave p.grad untouched views of that buffer."""
+        if self.eng is not None:
+            self.eng.grad_sink = None
+        for p in self.params:
+            p.grad = None
+
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
