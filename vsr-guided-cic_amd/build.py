@@ -32,6 +32,7 @@ def build(force=False, verbose=False):
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT + ".tmp", SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    cmd[1:1] = os.environ.get("VSR_EXTRA_HIPCC_FLAGS", "").split()         # diagnostics builds (-DATT_ABLATE=..., -DGEMM_STAMP, ...)
     subprocess.run(cmd, check=True)
     os.replace(OUT + ".tmp", OUT)
     return OUT

@@ -324,6 +324,9 @@ struct Gate2Args {
     float* g_t; float* hA_out;
 };
 
+#ifndef ATT_ABLATE
+#define ATT_ABLATE 0     // diagnostics builds only: 1 no slab sums, 2 no scores, 3 no weighted sum (results are then wrong)
+#endif
 template <int NT>
 __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* __restrict__ hA, const float* __restrict__ sa,
                                                 const float* __restrict__ sent, const float* __restrict__ P,
@@ -348,22 +351,72 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     const int k = slot ? slot[row] : fixed_slot;
     const long long sl = (long long)img * L + k;
     const bool fused = g2.c2a != nullptr;
-    if (fused) {
+    if (fused && ATT_ABLATE == 1) {
+        for (int c = tid; c < A; c += NT) { hA_s[c] = 0.01f; sa_s[c] = 0.02f; }
+        for (int c = tid; c < D; c += NT) sent_s[c] = 0.03f;
+    } else if (fused) {
+        // Slab sums of the S2 GEMM for this row.  FOUR columns per thread and pass with every slab load (and the g_t operands)
+        // issued before the first use: one column per loop iteration made each iteration's loads wait for the previous
+        // iteration's global store (8 dependent L2 round trips per row: 10 of the kernel's 34 us).
         const int H = g2.H;
-        for (int c = tid; c < H + A; c += NT) {
-            const float s = slab_sum(g2.c2a + (long long)row * (H + A) + c, g2.nsplit, g2.stride_a);
-            if (c < H) {
-                const long long o = (long long)row * H + c;
-                g2.g_t[o] = sigmoidf_(g2.gpre[o] + s) * tanhf(g2.c1n[o]);
-            } else {
-                hA_s[c - H] = s;
-                g2.hA_out[(long long)row * A + (c - H)] = s;
+        if (((H | A | D) & 3) == 0) {
+            // 16-byte path: four consecutive columns per thread, every slab load of a pass issued before the first use
+            for (int c = tid * 4; c < H + A; c += NT * 4) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < g2.nsplit) v[k] = *reinterpret_cast<const float4*>(g2.c2a + (long long)k * g2.stride_a + (long long)row * (H + A) + c);
+                float4 gp = make_float4(0, 0, 0, 0), cn = gp;
+                if (c < H) {
+                    gp = *reinterpret_cast<const float4*>(g2.gpre + (long long)row * H + c);
+                    cn = *reinterpret_cast<const float4*>(g2.c1n + (long long)row * H + c);
+                }
+                float4 s = v[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k)
+                    if (k < g2.nsplit) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+                if (c < H) {
+                    float4 o;
+                    o.x = sigmoidf_(gp.x + s.x) * tanhf(cn.x); o.y = sigmoidf_(gp.y + s.y) * tanhf(cn.y);
+                    o.z = sigmoidf_(gp.z + s.z) * tanhf(cn.z); o.w = sigmoidf_(gp.w + s.w) * tanhf(cn.w);
+                    *reinterpret_cast<float4*>(g2.g_t + (long long)row * H + c) = o;
+                } else {
+                    *reinterpret_cast<float4*>(hA_s + (c - H)) = s;
+                    *reinterpret_cast<float4*>(g2.hA_out + (long long)row * A + (c - H)) = s;
+                }
             }
-        }
-        for (int cc = tid; cc < D + A; cc += NT) {
-            const float s = slab_sum(g2.c2b + (long long)row * (D + A) + cc, g2.nsplit, g2.stride_b);
-            if (cc < D) sent_s[cc] = s + g2.b_sfc[cc];
-            else sa_s[cc - D] = s;
+            for (int cc = tid * 4; cc < D + A; cc += NT * 4) {
+                float4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < g2.nsplit) v[k] = *reinterpret_cast<const float4*>(g2.c2b + (long long)k * g2.stride_b + (long long)row * (D + A) + cc);
+                float4 s = v[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k)
+                    if (k < g2.nsplit) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+                if (cc < D) {
+                    const float4 bs = *reinterpret_cast<const float4*>(g2.b_sfc + cc);
+                    s.x += bs.x; s.y += bs.y; s.z += bs.z; s.w += bs.w;
+                    *reinterpret_cast<float4*>(sent_s + cc) = s;
+                } else {
+                    *reinterpret_cast<float4*>(sa_s + (cc - D)) = s;
+                }
+            }
+        } else {
+            for (int c = tid; c < H + A; c += NT) {
+                const float s = slab_sum(g2.c2a + (long long)row * (H + A) + c, g2.nsplit, g2.stride_a);
+                if (c < H) {
+                    g2.g_t[(long long)row * H + c] = sigmoidf_(g2.gpre[(long long)row * H + c] + s) * tanhf(g2.c1n[(long long)row * H + c]);
+                } else {
+                    hA_s[c - H] = s;
+                    g2.hA_out[(long long)row * A + (c - H)] = s;
+                }
+            }
+            for (int cc = tid; cc < D + A; cc += NT) {
+                const float s = slab_sum(g2.c2b + (long long)row * (D + A) + cc, g2.nsplit, g2.stride_b);
+                if (cc < D) sent_s[cc] = s + g2.b_sfc[cc];
+                else sa_s[cc - D] = s;
+            }
         }
     } else {
         for (int a = tid; a < A; a += NT) hA_s[a] = hA[(long long)row * A + a];
@@ -380,7 +433,8 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     // loads are all in flight before the first tanh (one L2 round trip per pass instead of one per row)
     const float* mk_row = rmask + sl * R;
     constexpr int QN = NT == 512 ? 5 : 4;        // rows per wave and pass: 8 waves x 5 cover the 37 score rows of R = 36 at once
-    for (int r0 = wave; r0 < R + 1; r0 += QN * NW) {
+    if (ATT_ABLATE == 2) { for (int j = tid; j < R + 1; j += NT) z_s[j] = 0.1f * j; }
+    for (int r0 = wave; r0 < R + 1 && ATT_ABLATE != 2; r0 += QN * NW) {
         float sc[QN];
 #pragma unroll
         for (int q = 0; q < QN; ++q) sc[q] = 0.f;
@@ -462,11 +516,11 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     // weighted sum.  Rows with alpha == 0 (zero padding) are skipped: no HBM read for them.  Four region rows are in
     // flight per thread (independent loads) so that the 8 KB rows stream instead of paying one L2/HBM latency each.
     const float a0 = z_s[0];
-    for (int d = tid * 4; d < D; d += 4 * NT) {
+    for (int d = tid * 4; d < D && ATT_ABLATE != 3; d += 4 * NT) {
         const float4 s = *reinterpret_cast<const float4*>(srow + d);
         float4 acc = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
         int r = 0;
-        constexpr int CH = 12;                     // region rows in flight per thread
+        constexpr int CH = 18;                     // region rows in flight per thread (two passes cover R = 36)
         for (; r + CH <= R; r += CH) {
             float al[CH];
             bool any = false;
