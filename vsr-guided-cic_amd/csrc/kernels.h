@@ -577,6 +577,7 @@ struct GateLogitArgs {
     const float* hA; const float* w_g; const float* zsum; const float* verbs; const int* slot;
     int rpi, L, M, A;
     float* lg; long long lg_stride;
+    float* ga_out = nullptr;                             // optional (M, A): the slab sums (the training forward saves them)
 };
 
 // one wave per row
@@ -600,6 +601,11 @@ __device__ __forceinline__ void gatelogit_row(const GateLogitArgs& g, int row, i
                 const int a = a0 + 64 * q;
                 if (a < g.A) x[q] += g.ga[k * g.stride + (long long)row * g.A + a];
             }
+        }
+        if (g.ga_out) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (a0 + 64 * q < g.A) g.ga_out[(long long)row * g.A + a0 + 64 * q] = x[q];
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
@@ -648,12 +654,6 @@ __device__ __forceinline__ void gatelogit_block(const GateLogitArgs& g, int row,
         g.lg[(long long)row * g.lg_stride + 1] = l1;
     }
     __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void k_gatelogit(const GateLogitArgs g) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= g.M) return;
-    gatelogit_row(g, row, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------------------------- vocab rows

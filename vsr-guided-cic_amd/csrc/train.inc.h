@@ -27,7 +27,7 @@ struct TrainCtx {
     int *word32, *slot32, *rows_bt;
     float *dlogits, *dh2_voc, *dpre1, *dpre2, *dhA_all, *dsent_all, *dsa_all, *dga_all, *dwa_rows, *dws_rows, *dwg_rows, *dP;
     float *dalpha;
-    float *datt, *dg_t, *dtc, *ds_t, *dh_tot, *dzsum, *dh1_c, *dh2_c, *dc1_c[2], *dc2_c[2], *dpre1sum, *dpre2sum, *dx_all;
+    float *datt, *dtc, *dh_tot, *dzsum, *dh1_c, *dh2_c, *dc1_c[2], *dc2_c[2], *dpre1sum, *dpre2sum, *dx_all;
     float *wT_ih1, *wT_is, *wT_ig, *wT_hh1, *wT_hs, *wT_ih2, *wT_hh2, *wT_hg, *wT_ha, *wT_sfc, *wT_sa, *wT_ga, *wT_out;
     float *tX_h2prev, *tX_x, *tX_h1prev, *tX_h1, *tX_att, *tX_st, *tX_gt, *tX_h2, *tX_vbar, *tX_reg;
     float *tY_dpre1, *tY_dpre2, *tY_dlogits, *tY_dhA, *tY_dsent, *tY_dsa, *tY_dga, *tY_dpre1sum, *tY_dpre2sum, *tY_dP;
@@ -65,7 +65,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.dhA_all = b.take<float>(TB * A); t.dsent_all = b.take<float>(TB * D); t.dsa_all = b.take<float>(TB * A); t.dga_all = b.take<float>(TB * A);
     t.dwa_rows = b.take<float>(TB * A); t.dws_rows = b.take<float>(TB * A); t.dwg_rows = b.take<float>(TB * A);
     t.dP = b.take<float>(RL * A);
-    t.datt = b.take<float>(B * D); t.dg_t = b.take<float>(B * H); t.dtc = b.take<float>(B * H); t.ds_t = b.take<float>(B * H);
+    t.datt = b.take<float>(B * D); t.dtc = b.take<float>(B * H);
     t.dh_tot = b.take<float>(B * H); t.dzsum = b.take<float>(B); t.dalpha = b.take<float>(B * R1);
     t.dh1_c = b.take<float>(B * H); t.dh2_c = b.take<float>(B * H);
     for (int i = 0; i < 2; ++i) { t.dc1_c[i] = b.take<float>(B * H); t.dc2_c[i] = b.take<float>(B * H); }
@@ -109,6 +109,11 @@ static int gemm_to(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, cons
     for (int i = 0; i < nseg; ++i) GemmBuilder::seg(p, segs[i].A, segs[i].lda, nullptr, segs[i].W, segs[i].ldw, segs[i].K);
     const int ns = g.finish(h);
     const long long stride = (long long)M * N;
+    if (ns == 1) {                          // every tile is produced by one workgroup: it writes the destination window itself
+        g.a.p[0].C = dst; g.a.p[0].ldc = (int)ldd; g.a.p[0].slab_stride = 0;
+        if (g.launch(s, h)) return fail("training gemm launch failed");
+        return 0;
+    }
     if ((size_t)stride * ns > t.scratch_floats) return fail("training scratch too small (%lld x %d)", stride, ns);
     g.a.p[0].slab_stride = stride;
     if (g.launch(s, h)) return fail("training gemm launch failed");
@@ -260,12 +265,12 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
             g.a.p[0].slab_stride = stride;
             g.a.p[1].C = gas; g.a.p[1].slab_stride = stride_g;
             if (g.launch(s, h)) return fail("train S5 gemm launch failed");
-            hipLaunchKernelGGL(k_lstm2_train, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
-                               w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, c2o, B, H, h2n, c2n, g2);
-            hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride_g, 256)), dim3(256), 0, s, gas, ns, stride_g, stride_g, ga);
-            hipLaunchKernelGGL(k_gatelogit, dim3(cdiv(B, 4)), dim3(256), 0, s,
-                               GateLogitArgs{ga, 1, stride_g, hA, w.att_g_weight, c.zsum, nullptr, slot, 1, c.L, B, A,
-                                             logp_gates + (size_t)tt * 2, (long long)T * 2});
+            GateLogitArgs gl{gas, ns, stride_g, hA, w.att_g_weight, c.zsum, nullptr, slot, 1, c.L, B, A,
+                             logp_gates + (size_t)tt * 2, (long long)T * 2};
+            gl.ga_out = ga;
+            const int gblocks = cdiv(B, 4);
+            hipLaunchKernelGGL(k_fwd_tail, dim3(gblocks + cdiv((long long)B * H, 256)), dim3(256), 0, s, gl, gblocks, c.scratch, ns, stride,
+                               w.lstm2_bias_ih, w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, c2o, B, H, h2n, c2n, g2);
         }
         LAUNCHCHK();
     }
@@ -378,8 +383,10 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     if (gemm_to1(h, t, s, TB, H, Vp, t.dlogits, Vp, t.wT_out, Vp, t.dh2_voc, H)) return 1;
     LAUNCHCHK();
 
-    // ---- phase A: reverse time
+    // ---- phase A: reverse time.  Per step: k_bwd_head, GEMM 1, k_bwd_mid, k_dalpha, k_attend_bwd, GEMM 2, k_bwd_tail, GEMM 3
     int cb = 0;
+    int ns3 = 0;                              // slabs of the later step's GEMM 3 waiting in t.scratch (consumed by k_bwd_head)
+    const long long st3 = (long long)B * H;
     for (int tt = T - 1; tt >= 0; --tt, cb ^= 1) {
         const float *c1 = t.c1s + (size_t)(tt + 1) * BH, *c1p = t.c1s + (size_t)tt * BH;
         const float *c2 = t.c2s + (size_t)(tt + 1) * BH, *c2p = t.c2s + (size_t)tt * BH;
@@ -394,19 +401,18 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         float* dga = t.dga_all + (size_t)tt * B * A;
         float *dwa = t.dwa_rows + (size_t)tt * B * A, *dws = t.dws_rows + (size_t)tt * B * A, *dwg = t.dwg_rows + (size_t)tt * B * A;
 
-        // gate log-probs -> dga, dhA (first writer), dzsum
-        hipLaunchKernelGGL(k_gatelogit_bwd, dim3(cdiv(B, 4)), dim3(256), 0, s, t.logp_g + (size_t)tt * 2, grad_logp_gates + (size_t)tt * 2,
-                           (long long)T * 2, ga, hA, w.att_g_weight, B, A, dga, dhA, t.dzsum, dwg);
-        // LSTM2
-        hipLaunchKernelGGL(k_add3, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.dh2_voc + (size_t)tt * BH, t.dh2_c, (const float*)nullptr,
-                           (long long)BH, t.dh_tot);
-        hipLaunchKernelGGL(k_lstm_bwd, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.dh_tot, t.dc2_c[cb], (const float*)nullptr, g2,
-                           (long long)4 * H, c2, tt > 0 ? c2p : (const float*)nullptr, B, H, dpre2, (long long)4 * H, t.dc2_c[cb ^ 1]);
-        // grouped GEMM 1: dpre2 -> [dh1_a | datt (| dvbar)] , dh2 carry (hh part);  dga -> dg_t
-        int ns1;
-        long long st0, st1, st2;
-        float *C0, *C1, *C2;
-        {
+        {   // gate log-probs -> dga, dhA (first writer), dzsum;  carries of step tt + 1 + vocabulary part -> LSTM2 backward
+            BwdHeadArgs q;
+            q.lg = t.logp_g + (size_t)tt * 2; q.dlg = grad_logp_gates + (size_t)tt * 2; q.lg_stride = (long long)T * 2;
+            q.ga = ga; q.hA = hA; q.w_g = w.att_g_weight; q.A = A;
+            q.dga = dga; q.dhA = dhA; q.dzsum = t.dzsum; q.dwg_rows = dwg; q.gblocks = cdiv(B, 4);
+            q.s_h1 = t.scratch; q.s_h2 = d.h2_first_lstm ? t.scratch + st3 * ns3 : nullptr; q.nslab3 = ns3; q.stride3 = st3;
+            q.dh1_c = t.dh1_c; q.dh2_c = t.dh2_c; q.dh2_voc = t.dh2_voc + (size_t)tt * BH;
+            q.dc_next = t.dc2_c[cb]; q.gates2 = g2; q.c2 = c2; q.c2_prev = tt > 0 ? c2p : nullptr;
+            q.M = B; q.H = H; q.dpre2 = dpre2; q.dc_prev = t.dc2_c[cb ^ 1];
+            hipLaunchKernelGGL(k_bwd_head, dim3(q.gblocks + cdiv((long long)BH, 256)), dim3(256), 0, s, q);
+        }
+        {   // grouped GEMM 1: dpre2 -> [dh1_a | datt (| dvbar)] , dh2 carry (hh part);  dga -> dg_t
             GemmBuilder g;
             GemmProb& p0 = g.prob(B, H + D, nullptr, H + D);
             GemmBuilder::seg(p0, dpre2, 4 * H, nullptr, t.wT_ih2, 4 * H, 4 * H);
@@ -414,24 +420,21 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             GemmBuilder::seg(p1, dpre2, 4 * H, nullptr, t.wT_hh2, 4 * H, 4 * H);
             GemmProb& p2 = g.prob(B, H, nullptr, H);
             GemmBuilder::seg(p2, dga, A, nullptr, t.wT_ga, A, A);
-            ns1 = g.finish(h);
-            st0 = (long long)B * (H + D); st1 = (long long)B * H; st2 = (long long)B * H;
-            C0 = t.scratch; C1 = C0 + st0 * ns1; C2 = C1 + st1 * ns1;
-            g.a.p[0].C = C0; g.a.p[0].slab_stride = st0;
-            g.a.p[1].C = C1; g.a.p[1].slab_stride = st1;
-            g.a.p[2].C = C2; g.a.p[2].slab_stride = st2;
+            const int ns1 = g.finish(h);
+            BwdMidArgs q;
+            q.nslab = ns1; q.st0 = (long long)B * (H + D); q.st1 = (long long)B * H; q.st2 = (long long)B * H;
+            float *C0 = t.scratch, *C1 = C0 + q.st0 * ns1, *C2 = C1 + q.st1 * ns1;
+            g.a.p[0].C = C0; g.a.p[0].slab_stride = q.st0;
+            g.a.p[1].C = C1; g.a.p[1].slab_stride = q.st1;
+            g.a.p[2].C = C2; g.a.p[2].slab_stride = q.st2;
             if (g.launch(s, h)) return fail("bwd gemm 1 launch failed");
-        }
-        {   // datt, dg_t, dh1 so far (= dh1_a + carry, into dh_tot) and the new dh2 carry (hh part; the LSTM1-input part is
-            // added after GEMM 3): one launch
-            SlabJobs jb;
-            jb.rows = B;
-            jb.j[0] = SlabJob{C0, ns1, st0, H + D, H, D, nullptr, t.datt};
-            jb.j[1] = SlabJob{C2, ns1, st2, H, 0, H, nullptr, t.dg_t};
-            jb.j[2] = SlabJob{C0, ns1, st0, H + D, 0, H, t.dh1_c, t.dh_tot};
-            jb.j[3] = SlabJob{C1, ns1, st1, H, 0, H, nullptr, t.dh2_c};
+            // datt; dg_t -> shift-gate backward (dq into dpre1[:, 5H:6H], dtc); dh1 so far (= dh1_a + carry, into dh_tot) and the
+            // hh part of the new dh2 carry (the LSTM1-input part is added by the next k_bwd_head from GEMM 3's slabs)
+            q.C0 = C0; q.C1 = C1; q.C2 = C2; q.M = B; q.H = H; q.D = D;
+            q.datt = t.datt; q.dh1_c = t.dh1_c; q.dh_tot = t.dh_tot; q.dh2_c = t.dh2_c;
+            q.gates1 = g1; q.c1 = c1; q.dq = dpre1 + 5 * H; q.dtc = t.dtc;
             const int wmax = D > H ? D : H;
-            hipLaunchKernelGGL(k_slab_cols_multi, dim3(cdiv((long long)B * wmax, 256), 4), dim3(256), 0, s, jb);
+            hipLaunchKernelGGL(k_bwd_mid, dim3(cdiv((long long)B * wmax, 256), 3), dim3(256), 0, s, q);
         }
         // attention
         {
@@ -443,10 +446,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             else hipLaunchKernelGGL(k_attend_bwd<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask,
                                slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws);
         }
-        // shift gate: dq into dpre1[:, 5H:6H], dtc
-        hipLaunchKernelGGL(k_gate2_bwd, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.dg_t, g1, (long long)6 * H, c1, B, H, dpre1 + 5 * H,
-                           (long long)6 * H, t.dtc);
-        // grouped GEMM 2: [dq | dhA] -> dh1_b ; [dsent | dsa] -> ds_t
+        // grouped GEMM 2: [dq | dhA] -> dh1_b ; [dsent | dsa] -> ds_t;  then the sentinel gate and LSTM1 pointwise backward
         {
             GemmBuilder g;
             GemmProb& p0 = g.prob(B, H, nullptr, H);
@@ -461,18 +461,11 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             g.a.p[0].C = Ca; g.a.p[0].slab_stride = st;
             g.a.p[1].C = Cb; g.a.p[1].slab_stride = st;
             if (g.launch(s, h)) return fail("bwd gemm 2 launch failed");
-            SlabJobs jb;
-            jb.rows = B;
-            jb.j[0] = SlabJob{Ca, ns, st, H, 0, H, t.dh_tot, t.dh_tot};
-            jb.j[1] = SlabJob{Cb, ns, st, H, 0, H, nullptr, t.ds_t};
-            hipLaunchKernelGGL(k_slab_cols_multi, dim3(cdiv((long long)BH, 256), 2), dim3(256), 0, s, jb);
+            hipLaunchKernelGGL(k_bwd_tail, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, Ca, Cb, ns, st, t.dh_tot, t.dtc, t.dc1_c[cb], g1, c1,
+                               tt > 0 ? c1p : (const float*)nullptr, B, H, dpre1, t.dc1_c[cb ^ 1]);
         }
-        // sentinel gate and LSTM1
-        hipLaunchKernelGGL(k_sgate_bwd, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.ds_t, g1, (long long)6 * H, c1, B, H, dpre1 + 4 * H,
-                           (long long)6 * H, t.dtc);
-        hipLaunchKernelGGL(k_lstm_bwd, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, t.dh_tot, t.dc1_c[cb], t.dtc, g1, (long long)6 * H, c1,
-                           tt > 0 ? c1p : (const float*)nullptr, B, H, dpre1, (long long)6 * H, t.dc1_c[cb ^ 1]);
-        // grouped GEMM 3: dpre1 -> dh2 carry (LSTM1 input part), dh1 carry
+        // grouped GEMM 3: dpre1 -> dh1 carry, dh2 carry (LSTM1 input part); its slabs stay in t.scratch for the next k_bwd_head
+        ns3 = 0;
         if (tt > 0) {
             GemmBuilder g;
             GemmProb& p1 = g.prob(B, H, nullptr, H);
@@ -484,16 +477,10 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
                 GemmBuilder::seg(p0, dpre1 + 4 * H, 6 * H, nullptr, t.wT_is, H, H);
                 GemmBuilder::seg(p0, dpre1 + 5 * H, 6 * H, nullptr, t.wT_ig, H, H);
             }
-            const int ns = g.finish(h);
-            const long long st = (long long)B * H;
-            g.a.p[0].C = t.scratch; g.a.p[0].slab_stride = st;
-            if (d.h2_first_lstm) { g.a.p[1].C = t.scratch + st * ns; g.a.p[1].slab_stride = st; }
+            ns3 = g.finish(h);
+            g.a.p[0].C = t.scratch; g.a.p[0].slab_stride = st3;
+            if (d.h2_first_lstm) { g.a.p[1].C = t.scratch + st3 * ns3; g.a.p[1].slab_stride = st3; }
             if (g.launch(s, h)) return fail("bwd gemm 3 launch failed");
-            SlabJobs jb;
-            jb.rows = B;
-            jb.j[0] = SlabJob{t.scratch, ns, st, H, 0, H, nullptr, t.dh1_c};
-            jb.j[1] = SlabJob{t.scratch + st * ns, ns, st, H, 0, H, t.dh2_c, t.dh2_c};
-            hipLaunchKernelGGL(k_slab_cols_multi, dim3(cdiv((long long)BH, 256), d.h2_first_lstm ? 2 : 1), dim3(256), 0, s, jb);
         }
         LAUNCHCHK();
     }

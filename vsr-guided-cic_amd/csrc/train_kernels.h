@@ -108,11 +108,6 @@ __global__ void k_colsum_finish(const float* __restrict__ part, int C, float* __
     out[c] = s;
 }
 
-__global__ void k_add_inplace(float* __restrict__ dst, const float* __restrict__ src, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] += src[i];
-}
-
 // gather of embedding rows for all steps: x_all[(t*B+b)] = embed[word_in[b][t]]
 __global__ void k_gather_rows(const float* __restrict__ table, const int* __restrict__ idx, int rows, int E, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,10 +182,18 @@ __global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long lo
     gates[base] = ig; gates[base + H] = fg; gates[base + 2LL * H] = gg; gates[base + 3LL * H] = og; gates[base + 4LL * H] = sg;
 }
 
-__global__ void k_lstm2_train(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ b_ih,
-                              const float* __restrict__ b_hh, const float* __restrict__ vproj2, const float* __restrict__ c2_old,
-                              int M, int H, float* __restrict__ h2n, float* __restrict__ c2n, float* __restrict__ gates) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// after the S5 GEMM, one launch: blocks [0, gblocks) finish att_ga(g_t) from its slabs (saved for the backward pass) and
+// write the step's gate log-probs, one wave per row; the other blocks are LSTM2 with its post-activation gates saved
+__global__ __launch_bounds__(256) void k_fwd_tail(const GateLogitArgs gl, int gblocks,
+                                                  const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ b_ih,
+                                                  const float* __restrict__ b_hh, const float* __restrict__ vproj2, const float* __restrict__ c2_old,
+                                                  int M, int H, float* __restrict__ h2n, float* __restrict__ c2n, float* __restrict__ gates) {
+    if ((int)blockIdx.x < gblocks) {
+        const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (row < gl.M) gatelogit_row(gl, row, threadIdx.x & 63);
+        return;
+    }
+    const long long i = (long long)(blockIdx.x - gblocks) * 256 + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
     const long long base = (long long)row * 4 * H + j;
@@ -209,75 +212,14 @@ __global__ void k_lstm2_train(const float* __restrict__ pre, int nsplit, long lo
     gates[base] = ig; gates[base + H] = fg; gates[base + 2LL * H] = gg; gates[base + 3LL * H] = og;
 }
 
-// reduce the att_ga slabs into ga (needed again by the backward pass)
-// (k_slab_reduce from kernels.h does it)
-
-// ---------------------------------------------------------------------------------------------- backward: outputs
-// dlogits = dlogp - exp(logp) * sum_v dlogp      (log_softmax backward, step :178), one block per row
-__global__ __launch_bounds__(256) void k_dlogits(const float* __restrict__ logp, const float* __restrict__ dlogp, int V,
-                                                 float* __restrict__ dlogits) {
-    __shared__ float red[4];
-    const long long row = blockIdx.x;
-    const int tid = threadIdx.x;
-    const float* g = dlogp + row * V;
-    const float* lp = logp + row * V;
-    float s = 0.f;
-    for (int v = tid; v < V; v += 256) s += g[v];
-    s = wave_sum(s);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
-    __syncthreads();
-    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-    for (int v = tid; v < V; v += 256) dlogits[row * V + v] = g[v] - expf(lp[v]) * tot;
-}
-
-// gate log-softmax + z_g backward (:184-188): one wave per row.
-//   d[z_g, zsum] = dlg - exp(lg) * (dlg0 + dlg1);  z_g = w_g . tanh(ga + hA)
-// writes dga (M,A) = dz_g * w_g * (1 - th^2), adds the same into dhA, accumulates dw_g, returns dzsum per row
-__global__ __launch_bounds__(256) void k_gatelogit_bwd(const float* __restrict__ lg, const float* __restrict__ dlg, long long lg_stride,
-                                                       const float* __restrict__ ga, const float* __restrict__ hA,
-                                                       const float* __restrict__ w_g, int M, int A, float* __restrict__ dga,
-                                                       float* __restrict__ dhA, float* __restrict__ dzsum, float* __restrict__ dwg_rows) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int lane = threadIdx.x & 63;
-    const float l0 = lg[row * lg_stride], l1 = lg[row * lg_stride + 1];
-    const float g0 = dlg[row * lg_stride], g1 = dlg[row * lg_stride + 1];
-    const float tot = g0 + g1;
-    const float dzg = g0 - expf(l0) * tot, dzs = g1 - expf(l1) * tot;
-    for (int a = lane; a < A; a += 64) {
-        const float th = tanhf(ga[(long long)row * A + a] + hA[(long long)row * A + a]);
-        const float du = dzg * w_g[a] * (1.f - th * th);
-        dga[(long long)row * A + a] = du;
-        dhA[(long long)row * A + a] = du;                 // first writer of dhA for this step
-        dwg_rows[(long long)row * A + a] = dzg * th;      // summed over rows later (k_colsum)
-    }
-    if (lane == 0) dzsum[row] = dzs;
-}
-
-// LSTM backward pointwise (used for both cells).  Inputs: dh (total gradient reaching h_t), dc_next (gradient reaching
-// c_t from step t+1), saved gates i,f,g,o (ld = gld, columns 0..4H), c_t, c_{t-1}; optional extra tanh(c) consumers:
-//   dtc_extra (gradient wrt tanh(c_t) from s_t / g_t paths, LSTM1 only).
-// Outputs: dpre (row, 4H) in columns [0,4H) of a (gld-wide) matrix, dc_prev.
-__global__ void k_lstm_bwd(const float* __restrict__ dh, const float* __restrict__ dc_next, const float* __restrict__ dtc_extra,
-                           const float* __restrict__ gates, long long gld, const float* __restrict__ c, const float* __restrict__ c_prev,
-                           int M, int H, float* __restrict__ dpre, long long dld, float* __restrict__ dc_prev) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)M * H) return;
-    const int row = (int)(i / H), j = (int)(i % H);
-    const float* g = gates + (long long)row * gld + j;
-    const float ig = g[0], fg = g[H], gg = g[2LL * H], og = g[3LL * H];
-    const float tc = tanhf(c[i]);
-    const float dhv = dh[i];
-    float dtc = dhv * og;
-    if (dtc_extra) dtc += dtc_extra[i];
-    const float dc = (dc_next ? dc_next[i] : 0.f) + dtc * (1.f - tc * tc);
-    float* d = dpre + (long long)row * dld + j;
-    d[0] = dc * gg * ig * (1.f - ig);
-    d[H] = dc * (c_prev ? c_prev[i] : 0.f) * fg * (1.f - fg);
-    d[2LL * H] = dc * ig * (1.f - gg * gg);
-    d[3LL * H] = dhv * tc * og * (1.f - og);
-    dc_prev[i] = dc * fg;
-}
+// ---------------------------------------------------------------------------------------------- backward
+// Pointwise formulas used by the fused step kernels further down:
+//   gate log-softmax + z_g (:184-188): d[z_g, zsum] = dlg - exp(lg) * (dlg0 + dlg1);  z_g = w_g . tanh(ga + hA);
+//       dga = dz_g * w_g * (1 - th^2) (also the first contribution to dhA), dw_g partial per row = dz_g * th
+//   LSTM cell (both cells): dtc = dh * o (+ gradient reaching tanh(c) from the s_t / g_t paths, LSTM1 only);
+//       dc = dc_next + dtc (1 - tanh^2 c);  dpre = [dc g i(1-i), dc c_prev f(1-f), dc i (1-g^2), dh tanh(c) o(1-o)];  dc_prev = dc f
+//   shift gate (:181-182): g_t = gg tanh(c1):  dq = dg_t tanh(c1) gg (1-gg),  dtc = dg_t gg
+//   sentinel gate (:151-154): s_t = sg tanh(c1):  ds_pre = ds_t tanh(c1) sg (1-sg),  dtc += ds_t sg
 
 // dalpha[row][j] = datt[row] . regions_j  (j = 0: sentinel), one WAVE per (row, j): B x (R+1) independent dot products
 // over D, so that a training batch of 100 rows still fills the chip (one workgroup per row left 60 % of the CUs idle).
@@ -411,40 +353,124 @@ __global__ __launch_bounds__(NT) void k_attend_bwd(const float* __restrict__ dat
     }
 }
 
-// shift-gate vector backward (:181-182): g_t = gg * tanh(c1), gg = sigmoid(gpre + hg) saved in gates[:, 5H:6H]
-//   in dg_t; out dq (M,H) = dg_t * tc * gg (1 - gg)  [gradient of the gate pre-activation], dtc (M,H) = dg_t * gg
-__global__ void k_gate2_bwd(const float* __restrict__ dg_t, const float* __restrict__ gates, long long gld, const float* __restrict__ c1,
-                            int M, int H, float* __restrict__ dq, long long dq_ld, float* __restrict__ dtc) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// ---------------------------------------------------------------------------------------------- fused step kernels
+// One backward step used to be 11 pointwise launches of ~5 us around its 3 GEMMs; the three kernels below do the same
+// arithmetic in the same order (bit-identical results) in 3 launches + k_dalpha + k_attend_bwd.
+//
+// k_bwd_head: (a) blocks [0, gblocks): gate log-softmax backward, one wave per row (the former k_gatelogit_bwd);
+//             (b) the remaining blocks, one thread per (row, j): finish the carries of the LATER step's GEMM 3 straight from its
+//                 slabs (dh1 carry -> dh1_c; LSTM1-input part of the dh2 carry added to the hh part in dh2_c), add the
+//                 vocabulary part of dh2 and run the LSTM2 pointwise backward.
+struct BwdHeadArgs {
+    const float* lg; const float* dlg; long long lg_stride; const float* ga; const float* hA; const float* w_g; int A;
+    float* dga; float* dhA; float* dzsum; float* dwg_rows; int gblocks;
+    const float* s_h1; const float* s_h2; int nslab3; long long stride3;    // GEMM 3 slabs of the later step (nslab3 = 0: none yet)
+    float* dh1_c; const float* dh2_c; const float* dh2_voc;
+    const float* dc_next; const float* gates2; const float* c2; const float* c2_prev;
+    int M, H; float* dpre2; float* dc_prev;
+};
+__global__ __launch_bounds__(256) void k_bwd_head(const BwdHeadArgs q) {
+    if ((int)blockIdx.x < q.gblocks) {
+        const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (row >= q.M) return;
+        const int lane = threadIdx.x & 63, A = q.A;
+        const float l0 = q.lg[row * q.lg_stride], l1 = q.lg[row * q.lg_stride + 1];
+        const float g0 = q.dlg[row * q.lg_stride], g1 = q.dlg[row * q.lg_stride + 1];
+        const float tot = g0 + g1;
+        const float dzg = g0 - expf(l0) * tot, dzs = g1 - expf(l1) * tot;
+        for (int a = lane; a < A; a += 64) {
+            const float th = tanhf(q.ga[(long long)row * A + a] + q.hA[(long long)row * A + a]);
+            const float du = dzg * q.w_g[a] * (1.f - th * th);
+            q.dga[(long long)row * A + a] = du;
+            q.dhA[(long long)row * A + a] = du;               // first writer of dhA for this step
+            q.dwg_rows[(long long)row * A + a] = dzg * th;    // summed over rows later (k_colsum)
+        }
+        if (lane == 0) q.dzsum[row] = dzs;
+        return;
+    }
+    const int H = q.H;
+    const long long i = (long long)(blockIdx.x - q.gblocks) * 256 + threadIdx.x;
+    if (i >= (long long)q.M * H) return;
+    const int row = (int)(i / H), j = (int)(i % H);
+    float carry = q.dh2_c[i];
+    if (q.nslab3 > 0) {
+        q.dh1_c[i] = slab_sum(q.s_h1 + i, q.nslab3, q.stride3);
+        if (q.s_h2) carry = slab_sum(q.s_h2 + i, q.nslab3, q.stride3, carry);
+    }
+    const float dhv = q.dh2_voc[i] + carry + 0.f;
+    const float* g = q.gates2 + (long long)row * 4 * H + j;
+    const float ig = g[0], fg = g[H], gg = g[2LL * H], og = g[3LL * H];
+    const float tc = tanhf(q.c2[i]);
+    const float dtc = dhv * og;
+    const float dc = q.dc_next[i] + dtc * (1.f - tc * tc);
+    float* d = q.dpre2 + (long long)row * 4 * H + j;
+    d[0] = dc * gg * ig * (1.f - ig);
+    d[H] = dc * (q.c2_prev ? q.c2_prev[i] : 0.f) * fg * (1.f - fg);
+    d[2LL * H] = dc * ig * (1.f - gg * gg);
+    d[3LL * H] = dhv * tc * og * (1.f - og);
+    q.dc_prev[i] = dc * fg;
+}
+
+// k_bwd_mid (after GEMM 1; grid.y = part): 0: datt = sum of the slabs' columns [H, H+D);  1: dg_t = sum of the att_ga slabs,
+// straight into the shift-gate backward (dq, dtc; the former k_gate2_bwd);  2: dh_tot = dh1_c + slabs' columns [0, H) and the
+// hh part of the new dh2 carry.
+struct BwdMidArgs {
+    const float* C0; const float* C1; const float* C2; int nslab; long long st0, st1, st2;
+    int M, H, D;
+    float* datt; const float* dh1_c; float* dh_tot; float* dh2_c;
+    const float* gates1; const float* c1; float* dq; float* dtc;          // gates1 (M,6H); dq window of ld 6H
+};
+__global__ __launch_bounds__(256) void k_bwd_mid(const BwdMidArgs q) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int H = q.H, D = q.D;
+    if (blockIdx.y == 0) {
+        if (i >= (long long)q.M * D) return;
+        const int r = (int)(i / D), c = (int)(i % D);
+        q.datt[i] = slab_sum(q.C0 + (long long)r * (H + D) + H + c, q.nslab, q.st0);
+        return;
+    }
+    if (i >= (long long)q.M * H) return;
+    const int r = (int)(i / H), c = (int)(i % H);
+    if (blockIdx.y == 1) {
+        const float d = slab_sum(q.C2 + i, q.nslab, q.st2);
+        const float tc = tanhf(q.c1[i]);
+        const float gg = q.gates1[(long long)r * 6 * H + 5LL * H + c];
+        q.dq[(long long)r * 6 * H + c] = d * tc * gg * (1.f - gg);
+        q.dtc[i] = d * gg;
+    } else {
+        q.dh_tot[i] = slab_sum(q.C0 + (long long)r * (H + D) + c, q.nslab, q.st0, q.dh1_c[i]);
+        q.dh2_c[i] = slab_sum(q.C1 + i, q.nslab, q.st1);
+    }
+}
+
+// k_bwd_tail (after GEMM 2): dh1 += slabs of [dq | dhA] . [W1_hg ; att_ha], ds_t = slabs of [dsent | dsa] . [s_fc ; att_sa], the
+// sentinel-gate backward and the LSTM1 pointwise backward (the former k_slab_cols_multi + k_sgate_bwd + k_lstm_bwd).
+__global__ __launch_bounds__(256) void k_bwd_tail(const float* __restrict__ Ca, const float* __restrict__ Cb, int nslab, long long st,
+                                                  const float* __restrict__ dh_tot, const float* __restrict__ dtc_in,
+                                                  const float* __restrict__ dc_next, const float* __restrict__ gates1,
+                                                  const float* __restrict__ c1, const float* __restrict__ c1_prev, int M, int H,
+                                                  float* __restrict__ dpre1, float* __restrict__ dc_prev) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
+    const float dhv = slab_sum(Ca + i, nslab, st, dh_tot[i]);
+    const float ds = slab_sum(Cb + i, nslab, st);
+    const float* g = gates1 + (long long)row * 6 * H + j;
+    const float ig = g[0], fg = g[H], gg = g[2LL * H], og = g[3LL * H], sg = g[4LL * H];
     const float tc = tanhf(c1[i]);
-    const float gg = gates[(long long)row * gld + 5LL * H + j];
-    const float d = dg_t[i];
-    dq[(long long)row * dq_ld + j] = d * tc * gg * (1.f - gg);
-    dtc[i] = d * gg;
+    float* d = dpre1 + (long long)row * 6 * H + j;
+    d[4LL * H] = ds * tc * sg * (1.f - sg);
+    const float extra = dtc_in[i] + ds * sg;
+    float dtc = dhv * og;
+    dtc += extra;
+    const float dc = dc_next[i] + dtc * (1.f - tc * tc);
+    d[0] = dc * gg * ig * (1.f - ig);
+    d[H] = dc * (c1_prev ? c1_prev[i] : 0.f) * fg * (1.f - fg);
+    d[2LL * H] = dc * ig * (1.f - gg * gg);
+    d[3LL * H] = dhv * tc * og * (1.f - og);
+    dc_prev[i] = dc * fg;
 }
 
-// sentinel gate backward (:151-154): s_t = s_gate * tanh(c1):  ds_pre = ds_t * tc * sg (1 - sg); dtc += ds_t * sg
-__global__ void k_sgate_bwd(const float* __restrict__ ds_t, const float* __restrict__ gates, long long gld, const float* __restrict__ c1,
-                            int M, int H, float* __restrict__ ds_pre, long long ld, float* __restrict__ dtc) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)M * H) return;
-    const int row = (int)(i / H), j = (int)(i % H);
-    const float sg = gates[(long long)row * gld + 4LL * H + j];
-    const float tc = tanhf(c1[i]);
-    const float d = ds_t[i];
-    ds_pre[(long long)row * ld + j] = d * tc * sg * (1.f - sg);
-    dtc[i] += d * sg;
-}
-
-// out = a + b (+ c)
-__global__ void k_add3(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, long long n, float* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = a[i] + (b ? b[i] : 0.f) + (c ? c[i] : 0.f);
-}
-
-// strided variant for slab sums: out[r][c] = sum_k slabs[k][r][c0 + c] (+ add[r][c])
 // (B, T) int64 captions / slot traces -> (T, B) int32 step-major copies, plus the (b, t)-ordered row list of the saved
 // states (row (t + 1) * B + b) that the batched vocabulary projection gathers through.  slots == null: slot = step.
 __global__ void k_train_indices(const int64_t* __restrict__ word_in, const int64_t* __restrict__ slots, int T, int B, int V, int L,
@@ -459,26 +485,6 @@ __global__ void k_train_indices(const int64_t* __restrict__ word_in, const int64
     word32[i] = (int)w;
     slot32[i] = (int)k;
     rows_bt[b * T + tt] = (tt + 1) * B + b;
-}
-
-// up to four k_slab_cols jobs of one backward step in one launch (grid.y = job): out = (add ? add : 0) + sum of the slabs'
-// column window [c0, c0 + w)
-struct SlabJob { const float* slabs; int nslab; long long stride; int ld, c0, w; const float* add; float* out; };
-struct SlabJobs { SlabJob j[4]; int rows; };
-__global__ void k_slab_cols_multi(const SlabJobs jobs) {
-    const SlabJob& q = jobs.j[blockIdx.y];
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)jobs.rows * q.w) return;
-    const int r = (int)(i / q.w), c = (int)(i % q.w);
-    q.out[i] = slab_sum(q.slabs + (long long)r * q.ld + q.c0 + c, q.nslab, q.stride, q.add ? q.add[i] : 0.f);
-}
-
-__global__ void k_slab_cols(const float* __restrict__ slabs, int nslab, long long stride, int ld, int c0, int w, int rows,
-                            const float* __restrict__ add, float* __restrict__ out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)rows * w) return;
-    const int r = (int)(i / w), c = (int)(i % w);
-    out[i] = slab_sum(slabs + (long long)r * ld + c0 + c, nslab, stride, add ? add[i] : 0.f);
 }
 
 }  // namespace vsr

@@ -1,15 +1,16 @@
 // libvsrcap.so - C ABI + per-timestep orchestration of the VSR captioning decoder on gfx950.
 // Entry points are declared in include/vsrcap.h; reference behaviour cited there and in kernels.h.
 //
-// One decoder timestep = 4 grouped fp32-MFMA GEMM launches + 6 small kernels, all on the caller's stream:
+// One decoder timestep = 4 grouped fp32-MFMA GEMM launches + 5 small kernels, all on the caller's stream:
 //   S1  [h2 | x | h1_old] -> LSTM1 gates (4H) | sentinel gate (H) | shift-gate image part (H)      gemm
 //       k_lstm1                                                                                    pointwise
 //   S2  h1_new -> [W1_hg | att_ha] ,  s_t -> [s_fc | att_sa]                                       gemm (4 problems)
-//       k_gate2, k_attend                                                                          pointwise / HBM-bound
+//       k_attend (shift-gate vector and the S2 slab sums fused in)                                 pointwise / HBM-bound
 //   S5  [h1_new | att | h2_old] -> LSTM2 gates (4H) ,  g_t -> att_ga                               gemm (2 problems)
-//       k_lstm2, k_gatelogit
+//       k_lstm2
 //   S6  h2_new -> vocabulary logits (V)                                                            gemm
-//       k_vocab (log-sum-exp + arg-max / top-k / Gumbel sample / full row), k_select_*
+//       k_vocab (log-sum-exp + arg-max / top-k / Gumbel sample / full row; the step's gate logits on the side), k_select_*
+// (the training forward, train.inc.h, keeps k_gate2 separate and saves what the backward pass needs)
 // The image-constant work (pooled descriptor and its projection, att_va(regions), row masks) is hoisted
 // into vsr_prepare().  Beams never copy statics: rows index their image (row / beam) and their parent.
 #include "../../include/vsrcap.h"
