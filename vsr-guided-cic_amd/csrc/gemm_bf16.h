@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "gemm_f32.h"
 
 namespace vsr {
@@ -46,18 +48,40 @@ __global__ void k_f32_to_bf16(const float* __restrict__ src, uint16_t* __restric
     }
 }
 
+#ifndef B16_ABLATE
+#define B16_ABLATE 0     // diagnostics only (tools/gemm_bench.hip): bit 0 = no global loads in the loop, bit 1 = no LDS refill, bit 2 = no epilogue stores
+#endif
 constexpr int B16_BK = 64;                                // k-tile: 64 bf16 = one 128-byte line per W row, two lines per fp32 A row
 
-template <int WM, int WN, int TM, int TN>      // waves WM x WN, wave tile (32 TM) x (32 TN)
-__global__ __launch_bounds__(64 * WM * WN)
+// Asynchronous 16-byte global loads.  The k loop keeps TWO tiles in flight per thread (two register sets).  Written with plain
+// C++ loads the compiler's waitcnt pass collapses that queue: it merges the "loads issued / not issued" paths of the loop and
+// then waits with vmcnt(<= 7) - i.e. for everything but the youngest quarter tile - before every LDS refill (measured: one, two
+// or three register sets, wave-specialised or not, all 2.7 us per k-tile).  So the loads are issued with inline asm, which the
+// pass does not track, and the waits are written by hand: vmcnt(N) = "all but the N youngest loads have landed" (loads return in
+// order).  Rules that keep this safe: every asm-loaded register is re-defined ("+v") right behind the wait, so no use can move
+// above it; the compiler's own VMEM operations (row gathers in open_segment, epilogue stores) only ever ADD waits; the epilogue
+// drains the queue (vmcnt(0)) before and after its stores, because stores share the counter.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void async_load16(f32x4_t& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+__device__ __forceinline__ void async_load16(u32x4_t& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_loads() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void landed(f32x4_t& d) { asm volatile("" : "+v"(d)); }
+__device__ __forceinline__ void landed(u32x4_t& d) { asm volatile("" : "+v"(d)); }
+
+// 16 waves: waves 0-7 MULTIPLY (2 x 4, 64 x 64 per wave, two per SIMD), waves 8-15 MOVE data (global -> registers -> bf16 -> LDS).
+// Why two kinds of waves: a CU pulls at most ~52 GB/s out of L2 (tools/gemm_bench feed: 1.26 us per 64 KB tile whatever the
+// queue depth, and only with all of its waves issuing loads), and a wave whose load cannot enter the memory pipeline stalls
+// at ISSUE - with one kind of wave the 1.26 us of feed, the 0.5 us LDS refill and the 1.1 us of ds_read + MFMA therefore add up
+// (2.7 us per k-tile, measured with one, two and three tiles in flight alike).  The movers take the stall, the multipliers keep
+// the matrix pipe busy; they meet at ONE barrier per k-tile, which then costs max(feed + refill, multiply).
+constexpr int B16_THREADS = 1024;
+__global__ __launch_bounds__(B16_THREADS)
 void gemm_nt_bf16w_kernel(const GemmArgs args) {
-    constexpr int NT = 64 * WM * WN;
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int BK = B16_BK;
-    constexpr int RPA = NT / 16, RPB = NT / 8;            // rows per load pass: 16 lanes x float4 / 8 lanes x 16 B cover a row's k-tile
-    constexpr int LA = BM / RPA, LB = BN / RPB;
-    static_assert(BM % RPA == 0 && BN % RPB == 0, "tile shape");
-    constexpr int BUF = (BM + BN) * B16_ROW;              // bf16 elements per k buffer
+    constexpr int WN = 4, TM = 2, TN = 2;                  // multipliers: 2 x 4 waves, wave tile 64 x 64
+    constexpr int BM = 128, BN = 256, BK = B16_BK;
+    constexpr int LA = BM / 32, LB = BN / 64;              // movers: 512 threads cover 32 A rows / 64 W rows per pass
+    constexpr int BUF = (BM + BN) * B16_ROW;               // bf16 elements per k buffer
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];
     auto sA = [&](int buf) { return smem + buf * BUF; };
     auto sB = [&](int buf) { return smem + buf * BUF + BM * B16_ROW; };
@@ -71,83 +95,10 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const bool mover = wave >= 8;
     const int r = lane & 31, hh = lane >> 5;
-    const int arow = tid >> 4, ak = (tid & 15) * 4;       // A: 16 lanes per row, 4 fp32 each (full 128-byte lines per wave instruction)
-    const int brow = tid >> 3, bk = (tid & 7) * 8;        // W: 8 lanes per row, 8 bf16 each
 
-    // ------------------------------------------------------------------ load cursor (runs TWO iterations ahead of the MFMAs)
-    float4 ra[LA];
-    uint4 rb[LB];
-    const float* pa[LA];
-    const uint16_t* pb[LB];
-    int l_prob = 0, l_tile = 0, l_tile_left = 0;
-    int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;
-    auto open_segment = [&](int s, int first_tile) __attribute__((always_inline)) {
-        const GemmProb& P = args.p[l_prob];
-        const GemmSeg& S = P.seg[s];
-        const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
-        l_seg = s;
-        l_K = S.K;
-        l_k = first_tile * BK;
-        l_seg_left = (S.K + BK - 1) / BK - first_tile;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            int m = m0 + arow + RPA * i;
-            m = m < P.M ? m : P.M - 1;
-            const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
-            pa[i] = S.A + row * S.lda + ak;
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            int n = n0 + brow + RPB * i;
-            n = n < P.N ? n : P.N - 1;
-            pb[i] = reinterpret_cast<const uint16_t*>(S.W) + (long long)n * S.ldw + bk;
-        }
-    };
-    auto open_tile = [&](int prob, int tile, int kt) __attribute__((always_inline)) {
-        l_prob = prob;
-        l_tile = tile;
-        const GemmProb& P = args.p[prob];
-        l_tile_left = P.ktiles - kt;
-        int s = 0;
-        while (s < P.nseg - 1 && kt >= (P.seg[s].K + BK - 1) / BK) { kt -= (P.seg[s].K + BK - 1) / BK; ++s; }
-        open_segment(s, kt);
-    };
-    int ka = 0, kb = 0;                                    // k offsets of the tile being loaded (0 in the K tail: a valid address)
-    bool ta = false, tb = false;                           // ... and whether this thread's piece lies in the tail (zeros are stored)
-    auto advance = [&]() __attribute__((always_inline)) {
-        if (l_tile_left == 0) {
-            if (l_tile + 1 < args.p[l_prob].tiles_m * args.p[l_prob].tiles_n) open_tile(l_prob, l_tile + 1, 0);
-            else open_tile(l_prob + 1, 0, 0);
-        } else if (l_seg_left == 0) {
-            open_segment(l_seg + 1, 0);
-        }
-        ta = !(l_k + ak < l_K);                            // K is a multiple of 8: a 4-float piece is inside or outside as a whole
-        tb = !(l_k + bk < l_K);
-        ka = ta ? 0 : l_k;
-        kb = tb ? 0 : l_k;
-        l_k += BK;
-        --l_seg_left;
-        --l_tile_left;
-    };
-    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = *reinterpret_cast<const float4*>(pa[i] + ka); };
-    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = *reinterpret_cast<const uint4*>(pb[i] + kb); };
-    bool sta = false, stb = false;                         // tail flags of the tile held in the registers
-    auto store_tile = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            uint2 o;
-            o.x = pack_bf16(ra[i].x, ra[i].y); o.y = pack_bf16(ra[i].z, ra[i].w);
-            if (sta) o = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2*>(sA(buf) + (arow + RPA * i) * B16_ROW + ak) = o;
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i)
-            *reinterpret_cast<uint4*>(sB(buf) + (brow + RPB * i) * B16_ROW + bk) = stb ? make_uint4(0u, 0u, 0u, 0u) : rb[i];
-    };
-
-    // ------------------------------------------------------------------ compute-side tile bookkeeping
+    // ------------------------------------------------------------------ tile bookkeeping (both kinds: the epilogue is shared)
     int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0;
     bool c_last = false;
     auto decode = [&](int it) __attribute__((always_inline)) {
@@ -169,38 +120,43 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
         return kt;
     };
 
-    // Epilogue of one tile piece.  Accumulator element e of subtile (ti, tj) is row (e & 3) + 8 (e >> 2) + 4 hh, column r (the
-    // C/D layout is dtype independent).  Bands of 32 tile rows go through the idle k buffer so that they leave as 16-byte row
-    // stores (dword stores from the registers cost the launch 40 % more: 60-80 MB of slab output per launch at M = 500).
+    // Epilogue of one tile piece.  Accumulator element e of subtile (ti, tj) is row (e & 3) + 8 (e >> 2) + 4 hh, column r.  Bands
+    // of 32 tile rows are staged in a k buffer by the four multiplier waves that own them and leave as 16-byte row stores issued
+    // by all 1024 threads (dword stores from the registers cost the launch 40 % more: 60-80 MB of slab output per launch).
     constexpr int ST_LD = BN + 4;
     static_assert(32 * ST_LD * 4 <= BUF * 2, "staging band must fit one k buffer");
-    auto flush = [&](const f32x16 (&acc)[TM][TN], float* stage) __attribute__((always_inline)) {
+    f32x16 acc[TM][TN];
+    auto flush = [&](auto MULT, float* stage) __attribute__((always_inline)) {
         const GemmProb& P = args.p[c_prob];
         const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
         float* C = P.C + (long long)c_piece * P.slab_stride;
         const int extra = c_last ? args.nslab - 1 - c_piece : 0;     // unused slabs of a finished tile: zeros
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
-        constexpr int TPR = BN / 4;                        // threads per staged row
-        constexpr int RPP = NT / TPR;                      // rows per store pass
+        constexpr int TPR = BN / 4;                        // 64 threads per staged row
+        constexpr int RPP = B16_THREADS / TPR;             // 16 rows per store pass
         const int c4 = (tid % TPR) * 4;
         const int n = n0 + c4;
+        const int wm = wave / WN, wn = wave % WN;          // (multipliers)
+        wait_loads<0>();                                   // stores share vmcnt with the asynchronous loads: start from an empty queue
 #pragma unroll
         for (int band = 0; band < BM / 32; ++band) {
+            if constexpr (decltype(MULT)::value) {
 #pragma unroll
-            for (int ti = 0; ti < TM; ++ti)
-                if (wm * TM + ti == band) {
+                for (int ti = 0; ti < TM; ++ti)
+                    if (wm * TM + ti == band) {
 #pragma unroll
-                    for (int tj = 0; tj < TN; ++tj)
+                        for (int tj = 0; tj < TN; ++tj)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e];
-                }
+                            for (int e = 0; e < 16; ++e)
+                                stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e];
+                    }
+            }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 32 / RPP; ++i) {
                 const int sr = tid / TPR + RPP * i;
                 const int m = m0 + band * 32 + sr;
-                if (m < P.M && n < P.N) {
+                if (m < P.M && n < P.N && !((B16_ABLATE & 4) && m + n > 0)) {
                     const float4 v = *reinterpret_cast<const float4*>(stage + sr * ST_LD + c4);
                     float* dst = C + (long long)m * P.ldc + n;
                     if (vec_ok && n + 3 < P.N) {
@@ -219,58 +175,162 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
             }
             __syncthreads();
         }
+        wait_loads<0>();                                   // ... and leave it empty (the hand-written waits count loads only)
+    };
+    // End of a k-tile for BOTH kinds of waves: the barrier, then - when the tile piece is complete - the epilogue, staged in the
+    // buffer the multipliers have just finished with (the movers wrote the OTHER one during this k-tile and touch this one only
+    // after the next barrier).
+    int cur = 0, it = it0;
+    auto end_of_ktile = [&](auto MULT) __attribute__((always_inline)) {
+        ++it;
+        const bool piece_done = --c_left == 0;
+        __syncthreads();
+        if (piece_done) {
+            flush(MULT, reinterpret_cast<float*>(sA(cur)));
+            if (it < it1) decode(it);
+        }
+        cur ^= 1;
+        return piece_done;
     };
 
-    // Pipeline: tile i is multiplied from LDS while tile i + 1 sits in registers and the loads of tile i + 2 are in flight.
-    //   iteration i:  [registers (tile i+1) -> bf16 -> the other LDS buffer]  [loads of tile i+2 between the MFMAs of tile i]  [barrier]
-    // A load therefore has a whole iteration to land, and its issue shares the iteration with the MFMAs instead of preceding them.
-    {
-        const int kt = decode(it0);
-        open_tile(c_prob, c_tile, kt);
-    }
-    advance();
+    const int kt0 = decode(it0);
+
+    if (mover) {
+        // ================================================================================================ movers
+        const int ptid = tid - 512;
+        const int arow = ptid >> 4, ak = (ptid & 15) * 4;  // A: 16 lanes per row, 4 fp32 each (whole 128-byte lines per wave instruction)
+        const int brow = ptid >> 3, bk = (ptid & 7) * 8;   // W: 8 lanes per row, 8 bf16 each
+        f32x4_t ra[2][LA];                                 // tile j (counted from it0) lives in register set j & 1
+        u32x4_t rb[2][LB];
+        bool sta[2] = {false, false}, stb[2] = {false, false};
+        const float* pa[LA];
+        const uint16_t* pb[LB];
+        int l_prob = 0, l_tile = 0, l_tile_left = 0;
+        int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;
+        auto open_segment = [&](int sg, int first_tile) __attribute__((always_inline)) {
+            const GemmProb& P = args.p[l_prob];
+            const GemmSeg& S = P.seg[sg];
+            const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
+            l_seg = sg;
+            l_K = S.K;
+            l_k = first_tile * BK;
+            l_seg_left = (S.K + BK - 1) / BK - first_tile;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) load_a(i);
+            for (int i = 0; i < LA; ++i) {
+                int m = m0 + arow + 32 * i;
+                m = m < P.M ? m : P.M - 1;
+                const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
+                pa[i] = S.A + row * S.lda + ak;
+            }
 #pragma unroll
-    for (int i = 0; i < LB; ++i) load_b(i);
-    sta = ta; stb = tb;
-    store_tile(0);
-    if (it0 + 1 < it1) {
-        advance();
+            for (int i = 0; i < LB; ++i) {
+                int n = n0 + brow + 64 * i;
+                n = n < P.N ? n : P.N - 1;
+                pb[i] = reinterpret_cast<const uint16_t*>(S.W) + (long long)n * S.ldw + bk;
+            }
+        };
+        auto open_tile = [&](int prob, int tile, int kt) __attribute__((always_inline)) {
+            l_prob = prob;
+            l_tile = tile;
+            const GemmProb& P = args.p[prob];
+            l_tile_left = P.ktiles - kt;
+            int sg = 0;
+            while (sg < P.nseg - 1 && kt >= (P.seg[sg].K + BK - 1) / BK) { kt -= (P.seg[sg].K + BK - 1) / BK; ++sg; }
+            open_segment(sg, kt);
+        };
+        int ka = 0, kb = 0;                                // k offsets of the tile being loaded (0 in the K tail: a valid address)
+        bool ta = false, tb = false;                       // ... and whether this thread's piece lies in the tail (zeros are stored)
+        auto advance = [&]() __attribute__((always_inline)) {
+            if (l_tile_left == 0) {
+                if (l_tile + 1 < args.p[l_prob].tiles_m * args.p[l_prob].tiles_n) open_tile(l_prob, l_tile + 1, 0);
+                else open_tile(l_prob + 1, 0, 0);
+            } else if (l_seg_left == 0) {
+                open_segment(l_seg + 1, 0);
+            }
+            ta = !(l_k + ak < l_K);                        // K is a multiple of 8: a piece is inside or outside as a whole
+            tb = !(l_k + bk < l_K);
+            ka = ta ? 0 : l_k;
+            kb = tb ? 0 : l_k;
+            l_k += BK;
+            --l_seg_left;
+            --l_tile_left;
+        };
+        // issue the loads of the next tile of the range into set S (asynchronous: nothing waits here)
+        auto issue = [&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            advance();
 #pragma unroll
-        for (int i = 0; i < LA; ++i) load_a(i);
+            for (int i = 0; i < LA; ++i) async_load16(ra[s][i], pa[i] + ka);
 #pragma unroll
-        for (int i = 0; i < LB; ++i) load_b(i);
-        sta = ta; stb = tb;
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int it = it0; it < it1;) {
-        f32x16 acc[TM][TN];
+            for (int i = 0; i < LB; ++i) async_load16(rb[s][i], pb[i] + kb);
+            sta[s] = ta; stb[s] = tb;
+        };
+        // set S has landed once at most the loads of the other (younger) set are still in flight
+        auto landed_set = [&](auto S, bool other_in_flight) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            if (other_in_flight) wait_loads<LA + LB>(); else wait_loads<0>();
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < LA; ++i) landed(ra[s][i]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < LB; ++i) landed(rb[s][i]);
+        };
+        auto store_tile = [&](auto S, int buf) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        const int n_it = c_left;
-        for (int j_it = 0; j_it < n_it; ++j_it, ++it) {
-            const bool more = it + 1 < it1, more2 = it + 2 < it1;
-            if (more) store_tile(cur ^ 1);                 // tile it + 1 (loaded one iteration ago): nobody reads that buffer now
-            if (more2) advance();
+            for (int i = 0; i < LA; ++i) {
+                uint2 o;
+                o.x = pack_bf16(ra[s][i].x, ra[s][i].y); o.y = pack_bf16(ra[s][i].z, ra[s][i].w);
+                if (sta[s]) o = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(sA(buf) + (arow + 32 * i) * B16_ROW + ak) = o;
+            }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                uint4 o = make_uint4(rb[s][i].x, rb[s][i].y, rb[s][i].z, rb[s][i].w);
+                if (stb[s]) o = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(sB(buf) + (brow + 64 * i) * B16_ROW + bk) = o;
+            }
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        // k-tile j:  [wait for tile j+1 (issued one k-tile ago; tile j+2 may stay in flight)] [tile j+1 -> bf16 -> the other buffer]
+        //            [issue tile j+3 into the set just emptied] [barrier]
+        open_tile(c_prob, c_tile, kt0);
+        issue(S0{});                                       // tile 0
+        landed_set(S0{}, false);
+        store_tile(S0{}, 0);
+        if (it0 + 1 < it1) issue(S1{});                    // tile 1
+        if (it0 + 2 < it1) issue(S0{});                    // tile 2
+        __syncthreads();                                   // buffer 0 is ready
+        auto step = [&](auto S) __attribute__((always_inline)) {
+            if (it + 1 < it1) {
+                landed_set(S, it + 2 < it1);
+                if (!(B16_ABLATE & 2)) store_tile(S, cur ^ 1);
+                if (it + 3 < it1 && !(B16_ABLATE & 1)) issue(S);
+            }
+            end_of_ktile(std::false_type{});
+        };
+        while (it < it1) {
+            step(S1{});
+            if (it < it1) step(S0{});
+        }
+    } else {
+        // ================================================================================================ multipliers
+        const int wm = wave / WN, wn = wave % WN;
+        auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        };
+        zero_acc();
+        __syncthreads();                                   // buffer 0 is ready
+        while (it < it1) {
             const uint16_t* a_base = sA(cur) + (wm * (32 * TM) + r) * B16_ROW + 8 * hh;
             const uint16_t* b_base = sB(cur) + (wn * (32 * TN) + r) * B16_ROW + 8 * hh;
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                if (more2) {                               // this k-step's share of the next-but-one tile's loads
-#pragma unroll
-                    for (int i = 0; i < LA; ++i)
-                        if (i * (BK / 16) / LA == kk) load_a(i);
-#pragma unroll
-                    for (int i = 0; i < LB; ++i)
-                        if (i * (BK / 16) / LB == kk) load_b(i);
-                }
+            for (int kk = 0; kk < ((B16_ABLATE & 8) ? 0 : BK / 16); ++kk) {
                 bf16x8_t av[TM], bv[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8_t*>(a_base + i * 32 * B16_ROW + kk * 16);
@@ -280,16 +340,9 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
             }
-            if (more2) { sta = ta; stb = tb; }
-            if (more) {
-                __syncthreads();
-                cur ^= 1;
-            }
+            if (end_of_ktile(std::true_type{})) zero_acc();
         }
-        flush(acc, reinterpret_cast<float*>(sA(cur ^ 1)));
-        if (it < it1) decode(it);
     }
 }
 

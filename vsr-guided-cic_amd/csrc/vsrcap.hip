@@ -273,11 +273,11 @@ struct GemmBuilder {
 };
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
-    dim3 grid(((a.G + 7) / 8) * 8), block(big == 16 || big == 32 || big == 33 ? 512 : 256);
+    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : big == 16 || big == 33 ? 512 : 256);
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
     if (big == 33) hipLaunchKernelGGL((gemm_nt_f32x3_kernel<2, 4, 2, 2>), grid, block, 0, s, a);
-    else if (big == 32) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<2, 4, 2, 2>), grid, block, 0, s, a);
+    else if (big == 32) hipLaunchKernelGGL(gemm_nt_bf16w_kernel, grid, block, 0, s, a);
     else if (big == 16) {
         switch (r16_tm) {
             case 1: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<1, 2>), grid, block, 0, s, a); break;
