@@ -39,15 +39,17 @@ __device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t&
     lo = pack_bf16(ar - am, br - bm);
 }
 
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN)
+// 16 waves per workgroup, like gemm_bf16.h: waves 0-7 MULTIPLY (2 x 4, 64 x 64 per wave, two per SIMD), waves 8-15 MOVE data
+// (asynchronous global loads two k-tiles ahead, the three-way split, ds_write into the buffer the multipliers are not reading);
+// one barrier per k-tile.  With one kind of wave (this file's first version, 8 waves) a k-tile cost
+// [load wait + split + LDS refill] + [18 ds_read + 24 MFMA per k-step] = 3.3 us; the X3_EXP ablations put 175 us of MFMA next to
+// 195 us of split / load / LDS time per decoder step, and those now overlap.
+constexpr int X3_THREADS = 1024;
+__global__ __launch_bounds__(X3_THREADS)
 void gemm_nt_f32x3_kernel(const GemmArgs args) {
-    constexpr int NT = 64 * WM * WN;
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr int BK = X3_BK;
-    constexpr int RP = NT / 8;                            // rows per load pass: 8 lanes x float4 cover a row's k-tile (one 128-byte line)
-    constexpr int LA = BM / RP, LB = BN / RP;
-    static_assert(BM % RP == 0 && BN % RP == 0, "tile shape");
+    constexpr int WN = 4, TM = 2, TN = 2;                  // multipliers: 2 x 4 waves, wave tile 64 x 64
+    constexpr int BM = 128, BN = 256, BK = X3_BK;
+    constexpr int LA = BM / 64, LB = BN / 64;              // movers: 512 threads cover 64 rows of a k-tile per pass
     constexpr int PLANE = (BM + BN) * X3_ROW;             // bf16 elements per plane
     constexpr int BUF = 3 * PLANE;                        // hi | mid | lo
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];           // 147 KB of the CU's 160 KB: one workgroup per CU
@@ -61,86 +63,8 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const bool mover = wave >= 8;
     const int r = lane & 31, hh = lane >> 5;
-    const int lrow = tid >> 3, lk = (tid & 7) * 4;        // this thread's row (per pass) and its 4 fp32 of the k-tile
-
-    float4 ra[LA], rb[LB];
-    const float* pa[LA];
-    const float* pb[LB];
-    int l_prob = 0, l_tile = 0, l_tile_left = 0;
-    int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;
-    auto open_segment = [&](int s, int first_tile) __attribute__((always_inline)) {
-        const GemmProb& P = args.p[l_prob];
-        const GemmSeg& S = P.seg[s];
-        const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
-        l_seg = s;
-        l_K = S.K;
-        l_k = first_tile * BK;
-        l_seg_left = (S.K + BK - 1) / BK - first_tile;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            int m = m0 + lrow + RP * i;
-            m = m < P.M ? m : P.M - 1;
-            const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
-            pa[i] = S.A + row * S.lda + lk;
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            int n = n0 + lrow + RP * i;
-            n = n < P.N ? n : P.N - 1;
-            pb[i] = S.W + (long long)n * S.ldw + lk;
-        }
-    };
-    auto open_tile = [&](int prob, int tile, int kt) __attribute__((always_inline)) {
-        l_prob = prob;
-        l_tile = tile;
-        const GemmProb& P = args.p[prob];
-        l_tile_left = P.ktiles - kt;
-        int s = 0;
-        while (s < P.nseg - 1 && kt >= (P.seg[s].K + BK - 1) / BK) { kt -= (P.seg[s].K + BK - 1) / BK; ++s; }
-        open_segment(s, kt);
-    };
-    int ko = 0;
-    bool tail = false;
-    auto advance = [&]() __attribute__((always_inline)) {
-        if (l_tile_left == 0) {
-            if (l_tile + 1 < args.p[l_prob].tiles_m * args.p[l_prob].tiles_n) open_tile(l_prob, l_tile + 1, 0);
-            else open_tile(l_prob + 1, 0, 0);
-        } else if (l_seg_left == 0) {
-            open_segment(l_seg + 1, 0);
-        }
-        tail = !(l_k + lk < l_K);                          // K is a multiple of 4
-        ko = tail ? 0 : l_k;
-        l_k += BK;
-        --l_seg_left;
-        --l_tile_left;
-    };
-    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = *reinterpret_cast<const float4*>(pa[i] + ko); };
-    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = *reinterpret_cast<const float4*>(pb[i] + ko); };
-    bool stail = false;
-    // row R of the tile (A rows first, then W rows), this thread's 4 k's: 8 bytes per plane at chunk (lk / 8) ^ ((R >> 2) & 3)
-    auto put = [&](uint16_t* buf, int R, float4 v) __attribute__((always_inline)) {
-        if (stail) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t h0, m0, l0, h1, m1, l1;
-#if X3_EXP == 1
-        h0 = __float_as_uint(v.x); m0 = __float_as_uint(v.y); l0 = 0; h1 = __float_as_uint(v.z); m1 = __float_as_uint(v.w); l1 = 0;
-#else
-        split3(v.x, v.y, h0, m0, l0);
-        split3(v.z, v.w, h1, m1, l1);
-#endif
-        const int pos = R * X3_ROW + 8 * ((lk >> 3) ^ ((R >> 2) & 3)) + (lk & 4);
-        *reinterpret_cast<uint2*>(buf + pos) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(buf + PLANE + pos) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(buf + 2 * PLANE + pos) = make_uint2(l0, l1);
-    };
-    auto store_tile = [&](int b) __attribute__((always_inline)) {
-        uint16_t* buf = smem + b * BUF;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) put(buf, lrow + RP * i, ra[i]);
-#pragma unroll
-        for (int i = 0; i < LB; ++i) put(buf, BM + lrow + RP * i, rb[i]);
-    };
 
     int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0;
     bool c_last = false;
@@ -165,27 +89,32 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
 
     constexpr int ST_LD = BN + 4;
     static_assert(32 * ST_LD * 4 <= BUF * 2, "staging band must fit one k buffer");
-    auto flush = [&](const f32x16 (&acc)[TM][TN], float* stage) __attribute__((always_inline)) {
+    f32x16 acc[TM][TN];
+    auto flush = [&](auto MULT, float* stage) __attribute__((always_inline)) {
         const GemmProb& P = args.p[c_prob];
         const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
         float* C = P.C + (long long)c_piece * P.slab_stride;
         const int extra = c_last ? args.nslab - 1 - c_piece : 0;
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
         constexpr int TPR = BN / 4;
-        constexpr int RPP = NT / TPR;
+        constexpr int RPP = X3_THREADS / TPR;
         const int c4 = (tid % TPR) * 4;
         const int n = n0 + c4;
+        const int wm = wave / WN, wn = wave % WN;          // (multipliers)
+        wait_loads<0>();                                   // stores share vmcnt with the asynchronous loads: start from an empty queue
 #pragma unroll
         for (int band = 0; band < BM / 32; ++band) {
+            if constexpr (decltype(MULT)::value) {
 #pragma unroll
-            for (int ti = 0; ti < TM; ++ti)
-                if (wm * TM + ti == band) {
+                for (int ti = 0; ti < TM; ++ti)
+                    if (wm * TM + ti == band) {
 #pragma unroll
-                    for (int tj = 0; tj < TN; ++tj)
+                        for (int tj = 0; tj < TN; ++tj)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e];
-                }
+                            for (int e = 0; e < 16; ++e)
+                                stage[((e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e];
+                    }
+            }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 32 / RPP; ++i) {
@@ -210,51 +139,159 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
             }
             __syncthreads();
         }
+        wait_loads<0>();                                   // ... and leave it empty (the hand-written waits count loads only)
+    };
+    // end of a k-tile for BOTH kinds of waves: barrier, epilogue when the tile piece is complete (staged in the buffer the
+    // multipliers have just finished with: the movers wrote the OTHER one during this k-tile)
+    int cur = 0, it = it0;
+    auto end_of_ktile = [&](auto MULT) __attribute__((always_inline)) {
+        ++it;
+        const bool piece_done = --c_left == 0;
+        __syncthreads();
+        if (piece_done) {
+            flush(MULT, reinterpret_cast<float*>(smem + cur * BUF));
+            if (it < it1) decode(it);
+        }
+        cur ^= 1;
+        return piece_done;
     };
 
-    {
-        const int kt = decode(it0);
-        open_tile(c_prob, c_tile, kt);
-    }
-    advance();
+    const int kt0 = decode(it0);
+
+    if (mover) {
+        // ================================================================================================ movers
+        const int ptid = tid - 512;
+        const int lrow = ptid >> 3, lk = (ptid & 7) * 4;   // 8 lanes x float4 cover a row's k-tile (one 128-byte line)
+        f32x4_t ra[2][LA], rb[2][LB];                      // tile j (counted from it0) lives in register set j & 1
+        bool stl[2] = {false, false};
+        const float* pa[LA];
+        const float* pb[LB];
+        int l_prob = 0, l_tile = 0, l_tile_left = 0;
+        int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;
+        auto open_segment = [&](int sg, int first_tile) __attribute__((always_inline)) {
+            const GemmProb& P = args.p[l_prob];
+            const GemmSeg& S = P.seg[sg];
+            const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
+            l_seg = sg;
+            l_K = S.K;
+            l_k = first_tile * BK;
+            l_seg_left = (S.K + BK - 1) / BK - first_tile;
 #pragma unroll
-    for (int i = 0; i < LA; ++i) load_a(i);
-#pragma unroll
-    for (int i = 0; i < LB; ++i) load_b(i);
-    stail = tail;
-    store_tile(0);
-    if (it0 + 1 < it1) {
-        advance();
-#pragma unroll
-        for (int i = 0; i < LA; ++i) load_a(i);
-#pragma unroll
-        for (int i = 0; i < LB; ++i) load_b(i);
-        stail = tail;
-    }
-    __syncthreads();
-    int cur = 0;
-    const int swz = (r >> 2) & 3;                          // rows 32 t + r of every subtile share it
-    for (int it = it0; it < it1;) {
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        const int n_it = c_left;
-        for (int j_it = 0; j_it < n_it; ++j_it, ++it) {
-            const bool more = it + 1 < it1, more2 = it + 2 < it1;
-            if (more) store_tile(cur ^ 1);                 // tile it + 1: split into the three planes of the idle buffer
-            if (more2) {
-                advance();
-                if (X3_EXP != 2) {
-#pragma unroll
-                    for (int i = 0; i < LA; ++i) load_a(i);
-#pragma unroll
-                    for (int i = 0; i < LB; ++i) load_b(i);
-                }
+            for (int i = 0; i < LA; ++i) {
+                int m = m0 + lrow + 64 * i;
+                m = m < P.M ? m : P.M - 1;
+                const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
+                pa[i] = S.A + row * S.lda + lk;
             }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                int n = n0 + lrow + 64 * i;
+                n = n < P.N ? n : P.N - 1;
+                pb[i] = S.W + (long long)n * S.ldw + lk;
+            }
+        };
+        auto open_tile = [&](int prob, int tile, int kt) __attribute__((always_inline)) {
+            l_prob = prob;
+            l_tile = tile;
+            const GemmProb& P = args.p[prob];
+            l_tile_left = P.ktiles - kt;
+            int sg = 0;
+            while (sg < P.nseg - 1 && kt >= (P.seg[sg].K + BK - 1) / BK) { kt -= (P.seg[sg].K + BK - 1) / BK; ++sg; }
+            open_segment(sg, kt);
+        };
+        int ko = 0;
+        bool tail = false;
+        auto advance = [&]() __attribute__((always_inline)) {
+            if (l_tile_left == 0) {
+                if (l_tile + 1 < args.p[l_prob].tiles_m * args.p[l_prob].tiles_n) open_tile(l_prob, l_tile + 1, 0);
+                else open_tile(l_prob + 1, 0, 0);
+            } else if (l_seg_left == 0) {
+                open_segment(l_seg + 1, 0);
+            }
+            tail = !(l_k + lk < l_K);                      // K is a multiple of 4
+            ko = tail ? 0 : l_k;
+            l_k += BK;
+            --l_seg_left;
+            --l_tile_left;
+        };
+        auto issue = [&](auto S) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            advance();
+#pragma unroll
+            for (int i = 0; i < LA; ++i) async_load16(ra[s][i], pa[i] + ko);
+#pragma unroll
+            for (int i = 0; i < LB; ++i) async_load16(rb[s][i], pb[i] + ko);
+            stl[s] = tail;
+        };
+        auto landed_set = [&](auto S, bool other_in_flight) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            if (other_in_flight) wait_loads<LA + LB>(); else wait_loads<0>();
+#pragma unroll
+            for (int i = 0; i < LA; ++i) landed(ra[s][i]);
+#pragma unroll
+            for (int i = 0; i < LB; ++i) landed(rb[s][i]);
+        };
+        // row R of the tile (A rows first, then W rows), this thread's 4 k's: 8 bytes per plane at chunk (lk / 8) ^ ((R >> 2) & 3)
+        auto put = [&](uint16_t* buf, int R, f32x4_t v, bool zero) __attribute__((always_inline)) {
+            if (zero) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            uint32_t h0, m0, l0, h1, m1, l1;
+#if X3_EXP == 1
+            h0 = __float_as_uint(v.x); m0 = __float_as_uint(v.y); l0 = 0; h1 = __float_as_uint(v.z); m1 = __float_as_uint(v.w); l1 = 0;
+#else
+            split3(v.x, v.y, h0, m0, l0);
+            split3(v.z, v.w, h1, m1, l1);
+#endif
+            const int pos = R * X3_ROW + 8 * ((lk >> 3) ^ ((R >> 2) & 3)) + (lk & 4);
+            *reinterpret_cast<uint2*>(buf + pos) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(buf + PLANE + pos) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(buf + 2 * PLANE + pos) = make_uint2(l0, l1);
+        };
+        auto store_tile = [&](auto S, int b) __attribute__((always_inline)) {
+            constexpr int s = decltype(S)::value;
+            uint16_t* buf = smem + b * BUF;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) put(buf, lrow + 64 * i, ra[s][i], stl[s]);
+#pragma unroll
+            for (int i = 0; i < LB; ++i) put(buf, BM + lrow + 64 * i, rb[s][i], stl[s]);
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        // k-tile j:  [wait for tile j+1 (issued one k-tile ago; tile j+2 may stay in flight)] [tile j+1 -> three planes of the other
+        //            buffer] [issue tile j+3 into the set just emptied] [barrier]
+        open_tile(c_prob, c_tile, kt0);
+        issue(S0{});                                       // tile 0
+        landed_set(S0{}, false);
+        store_tile(S0{}, 0);
+        if (it0 + 1 < it1) issue(S1{});                    // tile 1
+        if (it0 + 2 < it1) issue(S0{});                    // tile 2
+        __syncthreads();                                   // buffer 0 is ready
+        auto step = [&](auto S) __attribute__((always_inline)) {
+            if (it + 1 < it1) {
+                landed_set(S, it + 2 < it1);
+                store_tile(S, cur ^ 1);
+                if (it + 3 < it1 && X3_EXP != 2) issue(S);
+            }
+            end_of_ktile(std::false_type{});
+        };
+        while (it < it1) {
+            step(S1{});
+            if (it < it1) step(S0{});
+        }
+    } else {
+        // ================================================================================================ multipliers
+        const int wm = wave / WN, wn = wave % WN;
+        const int swz = (r >> 2) & 3;                      // rows 32 t + r of every subtile share it
+        auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        };
+        zero_acc();
+        __syncthreads();                                   // buffer 0 is ready
+        while (it < it1) {
             const uint16_t* base = smem + cur * BUF;
             const uint16_t* a_row = base + (wm * (32 * TM) + r) * X3_ROW;
             const uint16_t* b_row = base + (BM + wn * (32 * TN) + r) * X3_ROW;
@@ -289,14 +326,8 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }
-            if (more2) stail = tail;
-            if (more) {
-                __syncthreads();
-                cur ^= 1;
-            }
+            if (end_of_ktile(std::true_type{})) zero_acc();
         }
-        flush(acc, reinterpret_cast<float*>(smem + (cur ^ 1) * BUF));
-        if (it < it1) decode(it);
     }
 }
 

@@ -273,10 +273,10 @@ struct GemmBuilder {
 };
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
-    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : big == 16 || big == 33 ? 512 : 256);
+    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : big == 33 ? X3_THREADS : big == 16 ? 512 : 256);
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
-    if (big == 33) hipLaunchKernelGGL((gemm_nt_f32x3_kernel<2, 4, 2, 2>), grid, block, 0, s, a);
+    if (big == 33) hipLaunchKernelGGL(gemm_nt_f32x3_kernel, grid, block, 0, s, a);
     else if (big == 32) hipLaunchKernelGGL(gemm_nt_bf16w_kernel, grid, block, 0, s, a);
     else if (big == 16) {
         switch (r16_tm) {
