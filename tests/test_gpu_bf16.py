@@ -89,3 +89,32 @@ def test_bf16_needs_multiples_of_8():
     m.set_compute_dtype("f32")
     with torch.no_grad():
         m.test(det.to(DEV), ctrl.to(DEV))
+
+
+def test_bf16_k_aligned_plan_equals_stream_k_plan(monkeypatch):
+    """The 128 x 256 bf16 kernel under its two work decompositions (gemm_plan_aligned: one k-aligned piece of one tile per
+    workgroup; gemm_plan: stream-K ranges, VSR_GEMM_ALIGNED=0): the same bf16 products, only the fp32 order in which the k pieces
+    of a tile are added differs - log-probs (magnitude 5-60) within 1e-3 of each other (observed 2.3e-4), identical greedy tokens on the first 64 captions' first
+    5 steps (later steps may legitimately follow a flipped near-tie)."""
+    meta, _ = load_golden("g1_xe_wide")
+    cfg = meta["cfg"]
+    det, ctrl_seq, caps, _ = helpers.train_inputs(cfg, meta["seed"])
+    args = ((det.to(DEV),), (caps.to(DEV), ctrl_seq.to(DEV)))
+    metag, _ = load_golden("g2_greedy")
+    detg, ctrlg = helpers.decode_inputs(metag["cfg"], metag["seed"], 64)
+    outs, toks = [], []
+    for aligned in ("1", "0"):
+        monkeypatch.setenv("VSR_GEMM_ALIGNED", aligned)
+        m = _model(meta, gains=meta["gains"])            # a fresh model -> a fresh handle that reads the environment
+        m.set_compute_dtype("bf16")
+        with torch.no_grad():
+            out, gate = m(*args)
+        outs.append((out.cpu(), gate.cpu()))
+        mg = _model(metag)
+        mg.set_compute_dtype("bf16")
+        with torch.no_grad():
+            w, _ = mg.test(detg.to(DEV), ctrlg.to(DEV))
+        toks.append(w.cpu())
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-3
+    assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-3
+    assert torch.equal(toks[0][:, :5], toks[1][:, :5])

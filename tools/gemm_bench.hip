@@ -68,7 +68,9 @@ struct Builder {
         if (tm == 3300) { bm = 128; bn = 256; }                                      // f32x3 kernel
         if (tm > 1600 && tm <= 1608) { bm = 16 * (tm - 1600); bn = 64 * tn; }      // rows-16 kernel: tm = 1600 + TM, tn = TN
         if (tm == 1664) { bm = 128; bn = 256; }                                      // bf16 throughput kernel (bf16 W twins)
-        int ns = gemm_plan(a, slots, min_iters, bm, bn, tm == 1664 ? B16_BK : GEMM_BK);
+        int ns = 0;
+        if ((tm == 1664 || tm == 3300) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, tm == 1664 ? B16_BK : GEMM_BK);
+        if (!ns) ns = gemm_plan(a, slots, min_iters, bm, bn, tm == 1664 ? B16_BK : GEMM_BK);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
         return ns;
     }

@@ -53,6 +53,8 @@ struct GemmProb {
     int tiles_n;
     int ktiles;          // 32-wide k-tiles over all segments
     int it_begin;        // first global iteration of this problem
+    int g_begin;         // aligned plan only: first workgroup of this problem ...
+    int split;           // ... and the number of equal k pieces every one of its tiles is cut into
 };
 
 struct GemmArgs {
@@ -61,6 +63,7 @@ struct GemmArgs {
     int total_iters;
     int G;               // workgroups with a non-empty range (1 <= G <= total_iters); grid = 8 * ceil(G / 8)
     int nslab;           // slabs per tile (S)
+    int aligned;         // 0: stream-K ranges (gemm_plan); 1: one k-aligned piece of one tile per workgroup (gemm_plan_aligned)
     unsigned long long* dbg;   // diagnostics build only (GEMM_STAMP): per-workgroup {shader cycles, 100 MHz ticks}
 };
 
@@ -689,7 +692,85 @@ inline int gemm_plan(GemmArgs& a, int slots, int min_iters = 8, int BM = 64, int
     const int L = total / G;                       // shortest range
     a.nslab = G == 1 ? 1 : (kt_max + L - 1) / L + 1;
     if (a.nslab > 8) a.nslab = 8;
+    a.aligned = 0;
     return a.nslab;
+}
+
+// K-ALIGNED plan (the 128 x 256 kernels of gemm_bf16.h / gemm_f32x3.h): every tile of problem p is cut into split_p equal k
+// pieces and every workgroup takes exactly ONE piece of ONE tile; workgroups are numbered piece-major, tiles m-fastest, so the
+// 32 workgroups of an XCD (contiguous numbers) are neighbouring tiles AT THE SAME k: they walk the same weight / activation
+// k-windows at the same time and share them in L2, where the stream-K ranges (k offsets shifted from tile to tile) send almost
+// every tile load to the Infinity Cache.  The slab count is exact (max split) and a tile writes exactly
+// split_p slabs.  Chooses the smallest critical path T = max_p ceil(ktiles_p / split_p) with sum_p tiles_p split_p <= slots,
+// pieces of at least min_iters k-tiles, split <= 8.  Returns 0 (and leaves the plan untouched) when the tiles alone exceed the
+// slots: the caller then uses gemm_plan.
+inline int gemm_plan_aligned(GemmArgs& a, int slots, int min_iters, int BM, int BN, int BK) {
+    int tiles[4], kt[4], kt_max = 1, sum_tiles = 0;
+    for (int i = 0; i < a.nprob; ++i) {
+        const GemmProb& p = a.p[i];
+        tiles[i] = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+        kt[i] = 0;
+        for (int s = 0; s < p.nseg; ++s) kt[i] += (p.seg[s].K + BK - 1) / BK;
+        if (kt[i] > kt_max) kt_max = kt[i];
+        sum_tiles += tiles[i];
+    }
+    if (sum_tiles > slots || sum_tiles == 0) return 0;
+    int best_T = kt_max;
+    for (int T = kt_max; T >= 1; --T) {
+        int wgs = 0;
+        bool ok = true;
+        for (int i = 0; i < a.nprob && ok; ++i) {
+            const int s = (kt[i] + T - 1) / T;
+            ok = s <= 8 && (s == 1 || kt[i] / s >= min_iters);
+            wgs += tiles[i] * s;
+        }
+        if (!ok || wgs > slots) break;
+        best_T = T;
+    }
+    int total = 0, g = 0, nslab = 1;
+    for (int i = 0; i < a.nprob; ++i) {
+        GemmProb& p = a.p[i];
+        p.tiles_m = (p.M + BM - 1) / BM;
+        p.tiles_n = (p.N + BN - 1) / BN;
+        p.ktiles = kt[i];
+        p.it_begin = total;
+        total += tiles[i] * kt[i];
+        p.split = (kt[i] + best_T - 1) / best_T;
+        p.g_begin = g;
+        g += tiles[i] * p.split;
+        if (p.split > nslab) nslab = p.split;
+    }
+    a.total_iters = total;
+    a.G = g;
+    a.nslab = nslab;
+    a.aligned = 1;
+    return nslab;
+}
+
+// the k-tile range [it0, it1) of workgroup g (both plans) and, for the aligned plan, its problem / tile / piece
+struct GemmRange { int it0, it1, prob, tile, piece, split; };
+__device__ __forceinline__ GemmRange gemm_range(const GemmArgs& args, int g) {
+    GemmRange r;
+    if (!args.aligned) {
+        r.it0 = gemm_range_begin(g, args.total_iters, args.G);
+        r.it1 = gemm_range_begin(g + 1, args.total_iters, args.G);
+        r.prob = r.tile = r.piece = r.split = 0;
+        return r;
+    }
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < args.nprob && g >= args.p[i].g_begin) p = i;
+    const GemmProb& P = args.p[p];
+    const int local = g - P.g_begin, tiles = P.tiles_m * P.tiles_n;
+    r.prob = p;
+    r.piece = local / tiles;
+    r.tile = local - r.piece * tiles;
+    r.split = P.split;
+    const int base = P.it_begin + r.tile * P.ktiles;
+    r.it0 = base + (int)(((long long)r.piece * P.ktiles) / P.split);
+    r.it1 = base + (int)(((long long)(r.piece + 1) * P.ktiles) / P.split);
+    return r;
 }
 
 inline double gemm_flops(const GemmArgs& a) {

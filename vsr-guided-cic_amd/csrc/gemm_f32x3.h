@@ -57,8 +57,8 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
     const int G = args.G;
     const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
     if (g >= G) return;
-    const int it0 = gemm_range_begin(g, args.total_iters, G);
-    const int it1 = gemm_range_begin(g + 1, args.total_iters, G);
+    const GemmRange rg = gemm_range(args, g);
+    const int it0 = rg.it0, it1 = rg.it1;
     if (it0 >= it1) return;
 
     const int tid = threadIdx.x;
@@ -69,6 +69,12 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
     int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0;
     bool c_last = false;
     auto decode = [&](int it) __attribute__((always_inline)) {
+        if (args.aligned) {                                // one piece of one tile: nothing to search
+            c_prob = rg.prob; c_tile = rg.tile; c_piece = rg.piece;
+            c_left = it1 - it;
+            c_last = rg.piece == rg.split - 1;
+            return it - (args.p[rg.prob].it_begin + rg.tile * args.p[rg.prob].ktiles);
+        }
         int p = 0;
 #pragma unroll
         for (int i = 1; i < 4; ++i)

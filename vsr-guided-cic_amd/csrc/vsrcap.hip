@@ -115,6 +115,8 @@ struct vsr_handle {
     // shard of 12-13 images and its 65 beam rows, small eval batches) the 64-row tiles are mostly padding and the rows-16 kernel wins
     // (M = 13: 19.5 vs 13.2 TF/s over the four step GEMMs; beam-5 over a 13-image shard, M = 65: 3.48 vs 3.81 ms per call).
     int gemm_r16_max = 80;
+    int gemm_aligned = 1;        // 128 x 256 kernels: k-aligned pieces (gemm_plan_aligned) when the tiles fit the CUs; VSR_GEMM_ALIGNED=0: stream-K always
+    int gemm_aligned_min = 8;    // shortest piece, in 64-wide k-tiles (VSR_GEMM_ALIGNED_MIN)
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
     int gemm_tile = 0;           // 0 = by M; VSR_GEMM_TILE=64 | 12864 | 128 forces 64x64 / 128x64 / 128x128
     Ctx c;
@@ -239,6 +241,8 @@ struct GemmBuilder {
                 for (int i = 0; i < a.nprob; ++i)
                     for (int sg = 0; sg < a.p[i].nseg; ++sg) a.p[i].seg[sg].W = reinterpret_cast<const float*>(h->map16(a.p[i].seg[sg].W));
                 big = 32;
+                if (h->gemm_aligned)
+                    if (const int ns = gemm_plan_aligned(a, h->gemm_slots_bf16, h->gemm_aligned_min, 128, 256, B16_BK)) return ns;
                 return gemm_plan(a, h->gemm_slots_bf16, 4, 128, 256, B16_BK);
             }
         }
@@ -252,7 +256,7 @@ struct GemmBuilder {
                          ((reinterpret_cast<uintptr_t>(S.A) & 15) == 0);
                 }
             if (ok) {
-                big = 33;
+                big = 33;                              // (stream-K: this kernel is bound by its multipliers, the k-aligned plan's idle CUs cost more than its L2 hits save: 137 vs 121 us on S1)
                 return gemm_plan(a, h->gemm_slots_bf16, 4, 128, 256, X3_BK);
             }
         }
@@ -333,6 +337,8 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_GEMM_SLOTS_BF16")) h->gemm_slots_bf16 = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_R16")) h->gemm_slots_r16 = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_R16_MAX")) h->gemm_r16_max = atoi(e);
+    if (const char* e = getenv("VSR_GEMM_ALIGNED")) h->gemm_aligned = atoi(e);
+    if (const char* e = getenv("VSR_GEMM_ALIGNED_MIN")) h->gemm_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS")) h->gemm_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_SMALL")) h->gemm_slots_small = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e);
