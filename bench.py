@@ -310,7 +310,9 @@ def decode_bench(args, D, torch, dist, synth):
     dt = D.max_time(dt)
     images = c["B"] if strong else world * c["B"]
     name = "beam-5" if beam > 1 else "greedy"
-    traffic, tsrc = traffic_from_profiles("gemm") if (beam > 1 and not indexed and args.dtype == "f32") else (None, None)
+    traffic, tsrc = (None, None)
+    if beam > 1 and not indexed and args.dtype in ("f32", "bf16"):      # the workloads the committed PMC passes were taken on
+        traffic, tsrc = traffic_from_profiles("gemm" if args.dtype == "f32" else "gemm_bf16")
     line = {
         "metric": ("decoded tokens/sec at batch=100, beam=5, 36x2048 regions" + (", index-list region format" if indexed else ""))
                   if beam > 1 else "decoded tokens/sec, greedy, batch=100, 36x2048 regions",
