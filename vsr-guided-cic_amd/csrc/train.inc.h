@@ -130,11 +130,16 @@ static void colsum(TrainCtx& t, hipStream_t s, const float* X, long long ld, int
     hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), COLSUM_CHUNKS), dim3(256), 0, s, X, ld, R, C, t.scratch);
     hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(C, 256)), dim3(256), 0, s, t.scratch, C, out);
 }
-// out = in^T; in the bf16 mode a buffer with a registered bf16 twin (a GEMM W operand) receives bf16 in the twin instead
-static void transpose(vsr_handle* h, hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out) {
+// out = in^T (rows optionally gathered through `list`); in the bf16 mode a buffer with a registered bf16 twin (a GEMM W operand)
+// receives its bf16 image in the twin as well
+static void transpose(vsr_handle* h, hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out,
+                      const int* list = nullptr) {
     uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(out)) : nullptr;
-    if (tw) hipLaunchKernelGGL(k_transpose_bf16, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, in, ld_in, R, C, tw, ld_out, out);
-    else hipLaunchKernelGGL(k_transpose, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, s, in, ld_in, R, C, out, ld_out);
+    const dim3 grid(cdiv(C, 64), cdiv(R, 64)), block(256);
+    if (list && tw) hipLaunchKernelGGL((k_transpose_t<true, true>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, tw);
+    else if (list) hipLaunchKernelGGL((k_transpose_t<true, false>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, (uint16_t*)nullptr);
+    else if (tw) hipLaunchKernelGGL((k_transpose_t<false, true>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, tw);
+    else hipLaunchKernelGGL((k_transpose_t<false, false>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, (uint16_t*)nullptr);
 }
 
 extern "C" size_t vsr_train_workspace_bytes(const vsr_handle* h, int32_t B, int32_t T) {
@@ -499,11 +504,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     transpose(h, s, t.g_ts, H, TB, H, t.tX_gt, TBp);
     transpose(h, s, h2cur, H, TB, H, t.tX_h2, TBp);
     transpose(h, s, c.vbar, D, B, D, t.tX_vbar, Bp);
-    if (NV > 0) {
-        uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(t.tX_reg)) : nullptr;
-        if (tw) hipLaunchKernelGGL(k_transpose_gather_bf16, dim3(cdiv(D, 32), cdiv(NV, 32)), dim3(256), 0, s, c.regions, (long long)D, c.vlist, NV, D, tw, (long long)NVp, t.tX_reg);
-        else hipLaunchKernelGGL(k_transpose_gather, dim3(cdiv(D, 32), cdiv(NV, 32)), dim3(256), 0, s, c.regions, (long long)D, c.vlist, NV, D, t.tX_reg, (long long)NVp);
-    }
+    if (NV > 0) transpose(h, s, c.regions, (long long)D, NV, D, t.tX_reg, (long long)NVp, c.vlist);
     transpose(h, s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp);
     transpose(h, s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp);
     transpose(h, s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp);
@@ -511,7 +512,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     transpose(h, s, t.dsent_all, D, TB, D, t.tY_dsent, TBp);
     transpose(h, s, t.dsa_all, A, TB, A, t.tY_dsa, TBp);
     transpose(h, s, t.dga_all, A, TB, A, t.tY_dga, TBp);
-    if (NV > 0) hipLaunchKernelGGL(k_transpose_gather, dim3(cdiv(A, 32), cdiv(NV, 32)), dim3(256), 0, s, t.dP, (long long)A, c.vlist, NV, A, t.tY_dP, (long long)NVp);
+    if (NV > 0) transpose(h, s, t.dP, (long long)A, NV, A, t.tY_dP, (long long)NVp, c.vlist);
     hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 6 * H, 256)), dim3(256), 0, s, t.dpre1, T, (long long)B * 6 * H, t.dpre1sum);
     transpose(h, s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
     LAUNCHCHK();

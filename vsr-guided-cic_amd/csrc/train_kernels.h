@@ -11,67 +11,65 @@
 
 namespace vsr {
 
-// out (C, R) = in (R, C)^T, 32x32 tiles through LDS (both sides coalesced)
-__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, long long ld_in, int R, int C,
-                                                   float* __restrict__ out, long long ld_out) {
-    __shared__ float t[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8)
-        if (r0 + i < R && c0 + tx < C) t[i][tx] = in[(long long)(r0 + i) * ld_in + c0 + tx];
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8)
-        if (c0 + i < C && r0 + tx < R) out[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
-}
-
-// the same, written as bf16 (round-to-nearest-even): the bf16 mode's W operands (gemm_bf16.h)
+// Transposes, 64 x 64 tiles through LDS, 16 bytes per lane on both sides (256-byte row pieces; the 32 x 32 / 4-byte version
+// moved 1.5 TB/s).  GATHER: row r of the input is row list[r]; BF16: the bf16 image (round-to-nearest-even) goes to out16
+// - the bf16 mode's W operands (gemm_bf16.h) - and the fp32 image is written too (a launch that cannot take the bf16 kernel,
+// e.g. an odd alignment, runs on the fp32 one).  Unaligned shapes (ld or a base not a multiple of 4 floats) take scalar accesses.
 __device__ __forceinline__ uint16_t to_bf16_bits(float x) {
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 v = {x, 0.f};
     return (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2)) & 0xffffu);
 }
-// (the fp32 image is written too: a launch that cannot take the bf16 kernel - odd alignment - falls back to the fp32 one)
-__global__ __launch_bounds__(256) void k_transpose_bf16(const float* __restrict__ in, long long ld_in, int R, int C,
-                                                        uint16_t* __restrict__ out, long long ld_out, float* __restrict__ out32) {
-    __shared__ float t[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8)
-        if (r0 + i < R && c0 + tx < C) t[i][tx] = in[(long long)(r0 + i) * ld_in + c0 + tx];
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8)
-        if (c0 + i < C && r0 + tx < R) {
-            out[(long long)(c0 + i) * ld_out + r0 + tx] = to_bf16_bits(t[tx][i]);
-            out32[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
+template <bool GATHER, bool BF16>
+__global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int R, int C,
+                                                     float* __restrict__ out, long long ld_out, uint16_t* __restrict__ out16) {
+    __shared__ float t[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int q = threadIdx.x & 15, p = threadIdx.x >> 4;              // 16 lanes x 4 floats cover 64 columns; 16 rows per pass
+    const bool vin = ((ld_in & 3) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    const bool vout = ((ld_out & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                      (!BF16 || (reinterpret_cast<uintptr_t>(out16) & 7) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + p + 16 * i, c = c0 + 4 * q;
+        if (r < R) {
+            const float* src = in + (long long)(GATHER ? list[r] : r) * ld_in;
+            if (vin && c + 3 < C) {
+                const float4 v = *reinterpret_cast<const float4*>(src + c);
+                t[p + 16 * i][4 * q] = v.x; t[p + 16 * i][4 * q + 1] = v.y; t[p + 16 * i][4 * q + 2] = v.z; t[p + 16 * i][4 * q + 3] = v.w;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < C) t[p + 16 * i][4 * q + e] = src[c + e];
+            }
         }
-}
-__global__ __launch_bounds__(256) void k_transpose_gather_bf16(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int n,
-                                                               int C, uint16_t* __restrict__ out, long long ld_out, float* __restrict__ out32) {
-    __shared__ float t[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8)
-        if (r0 + i < n && c0 + tx < C) t[i][tx] = in[(long long)list[r0 + i] * ld_in + c0 + tx];
+    }
     __syncthreads();
-    for (int i = ty; i < 32; i += 8)
-        if (c0 + i < C && r0 + tx < n) {
-            out[(long long)(c0 + i) * ld_out + r0 + tx] = to_bf16_bits(t[tx][i]);
-            out32[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + p + 16 * i, r = r0 + 4 * q;                 // output row c, output columns r .. r + 3
+        if (c < C) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = t[4 * q + e][p + 16 * i];
+            float* dst = out + (long long)c * ld_out + r;
+            if (vout && r + 3 < R) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                if (BF16) {
+                    uint2 o;
+                    o.x = (uint32_t)to_bf16_bits(v[0]) | ((uint32_t)to_bf16_bits(v[1]) << 16);
+                    o.y = (uint32_t)to_bf16_bits(v[2]) | ((uint32_t)to_bf16_bits(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(out16 + (long long)c * ld_out + r) = o;
+                }
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (r + e < R) {
+                        dst[e] = v[e];
+                        if (BF16) out16[(long long)c * ld_out + r + e] = to_bf16_bits(v[e]);
+                    }
+            }
         }
-}
-
-// out (C, n) = rows list[0..n) of in (., C), transposed: out[c][j] = in[list[j]][c]
-__global__ __launch_bounds__(256) void k_transpose_gather(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int n,
-                                                          int C, float* __restrict__ out, long long ld_out) {
-    __shared__ float t[32][33];
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8)
-        if (r0 + i < n && c0 + tx < C) t[i][tx] = in[(long long)list[r0 + i] * ld_in + c0 + tx];
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8)
-        if (c0 + i < C && r0 + tx < n) out[(long long)(c0 + i) * ld_out + r0 + tx] = t[tx][i];
+    }
 }
 
 // dst (rows, w) window with leading dimension ldd  =  sum of nslab compact (rows, w) slabs
