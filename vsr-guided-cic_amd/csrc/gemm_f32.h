@@ -75,6 +75,33 @@ constexpr int GEMM_LDS = GEMM_BK + 4;
 
 __device__ __host__ inline int gemm_range_begin(int g, int total, int G) { return (int)(((long long)g * total) / G); }
 
+// the k-tile range [it0, it1) of workgroup g (both plans) and, for the aligned plan, its problem / tile / piece
+struct GemmRange { int it0, it1, prob, tile, piece, split; };
+__device__ __forceinline__ GemmRange gemm_range(const GemmArgs& args, int g) {
+    GemmRange r;
+    if (!args.aligned) {
+        r.it0 = gemm_range_begin(g, args.total_iters, args.G);
+        r.it1 = gemm_range_begin(g + 1, args.total_iters, args.G);
+        r.prob = r.tile = r.piece = r.split = 0;
+        return r;
+    }
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < args.nprob && g >= args.p[i].g_begin) p = i;
+    const GemmProb& P = args.p[p];
+    const int local = g - P.g_begin, tiles = P.tiles_m * P.tiles_n;
+    r.prob = p;
+    r.piece = local / tiles;
+    r.tile = local - r.piece * tiles;
+    r.split = P.split;
+    const int base = P.it_begin + r.tile * P.ktiles;
+    r.it0 = base + (int)(((long long)r.piece * P.ktiles) / P.split);
+    r.it1 = base + (int)(((long long)(r.piece + 1) * P.ktiles) / P.split);
+    return r;
+}
+
+
 // TM x TN 32x32 MFMA tiles per wave, WM x WN waves per workgroup; workgroup tile = (32 TM WM) x (32 TN WN)
 // Occupancy is LDS-bound (160 KB / (2 (BM + BN) 36 4 B) workgroups per CU); telling the register allocator so
 // keeps it from spilling the in-flight tile to scratch in pursuit of waves the LDS could never host.
@@ -745,32 +772,6 @@ inline int gemm_plan_aligned(GemmArgs& a, int slots, int min_iters, int BM, int 
     a.nslab = nslab;
     a.aligned = 1;
     return nslab;
-}
-
-// the k-tile range [it0, it1) of workgroup g (both plans) and, for the aligned plan, its problem / tile / piece
-struct GemmRange { int it0, it1, prob, tile, piece, split; };
-__device__ __forceinline__ GemmRange gemm_range(const GemmArgs& args, int g) {
-    GemmRange r;
-    if (!args.aligned) {
-        r.it0 = gemm_range_begin(g, args.total_iters, args.G);
-        r.it1 = gemm_range_begin(g + 1, args.total_iters, args.G);
-        r.prob = r.tile = r.piece = r.split = 0;
-        return r;
-    }
-    int p = 0;
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-        if (i < args.nprob && g >= args.p[i].g_begin) p = i;
-    const GemmProb& P = args.p[p];
-    const int local = g - P.g_begin, tiles = P.tiles_m * P.tiles_n;
-    r.prob = p;
-    r.piece = local / tiles;
-    r.tile = local - r.piece * tiles;
-    r.split = P.split;
-    const int base = P.it_begin + r.tile * P.ktiles;
-    r.it0 = base + (int)(((long long)r.piece * P.ktiles) / P.split);
-    r.it1 = base + (int)(((long long)(r.piece + 1) * P.ktiles) / P.split);
-    return r;
 }
 
 inline double gemm_flops(const GemmArgs& a) {
