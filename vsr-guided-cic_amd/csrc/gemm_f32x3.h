@@ -24,7 +24,7 @@
 namespace vsr {
 
 #ifndef X3_EXP
-#define X3_EXP 0      // diagnostics (tools/gemm_bench.hip): 1 no split, 2 no global loads in the loop, 3 one MFMA term of six
+#define X3_EXP 0      // diagnostics (tools/gemm_bench.hip): 1 no split, 2 no global loads in the loop, 3 one MFMA term of six, 5 no operand reads from LDS
 #endif
 constexpr int X3_BK = 32;
 constexpr int X3_ROW = 32;                               // bf16 elements per LDS row (64 bytes, unpadded, XOR-swizzled chunks)
@@ -305,6 +305,9 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
             for (int kk = 0; kk < BK / 16; ++kk) {
                 const int ch = 8 * ((2 * kk + hh) ^ swz);  // lane (r, hh) reads k = 8 hh + 16 kk .. +7: chunk 2 kk + hh, swizzled
                 bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#if X3_EXP == 5
+                if (it > it0 + 1000000) {                  // diagnostics: operands never re-read from LDS
+#endif
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[i] = *reinterpret_cast<const bf16x8_t*>(a_row + i * 32 * X3_ROW + ch);
@@ -317,6 +320,12 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
                     bm[j] = *reinterpret_cast<const bf16x8_t*>(b_row + PLANE + j * 32 * X3_ROW + ch);
                     bl[j] = *reinterpret_cast<const bf16x8_t*>(b_row + 2 * PLANE + j * 32 * X3_ROW + ch);
                 }
+#if X3_EXP == 5
+                } else {
+                    for (int i = 0; i < TM; ++i) { asm volatile("" : "=v"(ah[i])); asm volatile("" : "=v"(am[i])); asm volatile("" : "=v"(al[i])); }
+                    for (int j = 0; j < TN; ++j) { asm volatile("" : "=v"(bh[j])); asm volatile("" : "=v"(bm[j])); asm volatile("" : "=v"(bl[j])); }
+                }
+#endif
                 // smallest terms first, the leading product last
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
