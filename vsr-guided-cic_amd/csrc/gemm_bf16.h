@@ -8,12 +8,13 @@
 // every optimizer step from the fp32 master weights; transposed weights / transposed activations of the backward pass:
 // written as bf16 by the transposing kernels).  Matrix instruction: v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).
 //
-// At that rate the k loop is bound by the bytes a CU can pull from L2 into LDS (measured ~22 GB/s per CU in the fp32 kernel,
-// DESIGN.md section 4), so the tile is chosen for flop per loaded byte, not for the matrix pipe: 128 (M) x 256 (N) x 32 with
-// 8 waves (2 x 4, 64 x 64 per wave) loads 16 KB of fp32 A + 16 KB of bf16 W per 2.1 Mflop = 65 flop / byte, 3x the fp32
-// 128x64 tile.  LDS rows are 32 bf16 + 8 pad = 80 bytes: the ds_read_b128 lane groups of the 32x32x16 operand map
-// (lane r = l & 31 reads row r, k = 8 (l >> 5) .. +7) hit 64 distinct banks.  Stream-K decomposition, slab outputs and
-// cursor are those of gemm_nt_f32_kernel; the epilogue stores accumulator registers directly (128-byte runs per half wave).
+// At that rate the k loop is bound by the bytes a CU can pull from L2 into LDS (~52 GB/s per CU at best, tools/gemm_bench feed), so
+// the tile is chosen for flop per loaded byte, not for the matrix pipe: 128 (M) x 256 (N) x 64 (K) loads 32 KB of fp32 A + 32 KB
+// of bf16 W per 4.2 Mflop = 65 flop / byte, 3x the fp32 128x64 tile.  LDS rows are 64 bf16 + 8 pad = 144 bytes (36 dwords, the
+// fp32 kernel's conflict-free stride for the ds_read_b128 lane groups of the 32x32x16 operand map: lane r = l & 31 reads row r,
+// k = 8 (l >> 5) .. +7).  16 waves per workgroup - 8 multiply, 8 move data - and asynchronous loads with hand-written waits
+// (both explained at the kernel); two work decompositions: stream-K ranges (gemm_plan) or one k-aligned piece of one tile per
+// workgroup (gemm_plan_aligned, used whenever the tiles fit the CUs); slab outputs; LDS-staged 16-byte epilogue stores.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

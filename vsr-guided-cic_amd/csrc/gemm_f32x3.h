@@ -11,7 +11,7 @@
 //
 // Why: six bf16 MFMAs cost 6/16 of the fp32 MFMA time, so the kernel can afford the tile that halves the bytes per flop
 // (128 x 256 x 32, 43 flop per loaded byte against 21 for the fp32 kernel's 128 x 64) - the fp32 kernel is pinned at 0.65 of
-// its MFMA peak by the chip.  Structure = gemm_bf16.h: 8 waves (2 x 4, 64 x 64 per wave), whole-line
+// its MFMA peak by the chip.  Structure = gemm_bf16.h: 16 waves (8 multiply 64 x 64 each, 8 move data), whole-line
 // loads, loads issued two tiles ahead, LDS-staged epilogue.  LDS: three bf16 planes of (128 + 256) rows x 32, rows unpadded
 // (64 bytes), 16-byte chunk c of row r at position c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 for the 32x32x16 operand
 // map), double buffered: 147 KB.

@@ -91,7 +91,7 @@ struct vsr_handle {
     bool x3_on = false;               // fp32 products through three bf16 terms per operand (gemm_f32x3.h); fp32 operands, no copies
     std::vector<Bf16Range> b16;        // weights (refresh) + the training pass's transposed operands (carve_train)
     size_t b16_weights = 0;            // entries of b16 that belong to the weights
-    int gemm_slots_bf16 = 256;         // ONE 8-wave workgroup per CU (108 KB of LDS: two 128+256-row x 64-k bf16 buffers)
+    int gemm_slots_bf16 = 256;         // ONE 16-wave workgroup per CU (108 KB of LDS: two 128+256-row x 64-k bf16 buffers; 147 KB for f32x3)
     const uint16_t* map16(const float* p) const {
         for (const Bf16Range& r : b16)
             if (p >= r.lo && p < r.hi) return r.b + (p - r.lo);
