@@ -59,3 +59,17 @@ def test_synth_is_deterministic_and_padded():
     assert ((nz[:, :, 1:] <= nz[:, :, :-1])).all()  # valid rows first, zero padding after
     d = synth.make_detections(5, 12, 256, seed=9)
     assert ((d.sum(-1) != 0).sum(1) >= 1).all()
+
+
+def test_empty_batch_follows_the_reference():
+    """reference probed here (CPU, torch 2.10): test() on a batch of 0 images returns (0, T) int64 outputs; beam_search and
+    sample_rl raise RuntimeError (a reshape of 0 elements) - ours raise RuntimeError too (no kernel is launched for B = 0)."""
+    from models import ControllableCaptioningModel
+    m = ControllableCaptioningModel(6, 30, 2, det_feat_size=16, input_encoding_size=8, rnn_size=8, att_size=4, verb_2_vob_all={})
+    det, ctrl = torch.rand(0, 5, 16), torch.rand(0, 3, 5, 16)
+    w, g = m.test(det, ctrl)
+    assert w.shape == (0, 6) and g.shape == (0, 6) and w.dtype == torch.int64 and g.dtype == torch.int64
+    with pytest.raises(RuntimeError):
+        m.beam_search((det, ctrl), [3, -1], 3, 1)
+    with pytest.raises(RuntimeError):
+        m.sample_rl(det, ctrl)

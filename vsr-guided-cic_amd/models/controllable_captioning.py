@@ -171,6 +171,9 @@ class ControllableCaptioningModel(CaptioningModel):
         """test() of the reference takes (detections, ctrl_det_seqs_test) only (:299); a third static (verb list) is an
         extension that runs the greedy loop over step_v (gt=False) == beam_search_v with beam_size 1."""
         det, ctrl = statics[0], statics[1]
+        if det.shape[0] == 0:        # the reference's test() unrolls over an empty batch and returns (0, T) outputs (CaptioningModel.py:38-52)
+            e = torch.zeros(0, self.seq_len, dtype=torch.int64, device=det.device)
+            return e, e.clone()
         eng = self._engine(det.device)
         B = self._prepare(eng, det, ctrl, 1)
         v = self._verbs(eng, statics[2], det.device, B, self._n_slots(ctrl)) if len(statics) > 2 and statics[2] is not None else None
