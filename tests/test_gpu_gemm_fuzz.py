@@ -1,0 +1,21 @@
+"""The grouped GEMM kernels on their own, outside the decoder: tools/gemm_bench `fuzz` launches random ragged grouped problems
+(1-3 problems of 1-3 k segments, row gathers, K tails, odd leading dimensions and offsets of the output window, 8-256 workgroup
+slots, stream-K ranges and k-aligned pieces) and compares the slab sums with an fp64 host reference; columns outside the output
+window must stay untouched.  Variants: the fp32 64x64 / 128x64 / 128x128 kernels, the rows-16 kernel, and the two 16-wave kernels
+with hand-written asynchronous loads (bf16: tolerance of bf16 operands; f32x3: fp32 tolerance)."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOOL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gemm_bench")
+
+
+@pytest.mark.parametrize("variant", ["1 1", "121 1", "2 2", "1605 2", "1607 2", "1664 1", "3300 1"])
+def test_gemm_variant_on_random_ragged_launches(variant):
+    if not os.path.exists(TOOL):
+        pytest.skip("tools/gemm_bench not built (python vsr-guided-cic_amd/build.py --tool, or __graft_entry__.build())")
+    r = subprocess.run([TOOL, "fuzz"] + variant.split() + ["16", "5"], capture_output=True, text=True, timeout=600)
+    tail = "\n".join(r.stdout.splitlines()[-20:])
+    assert r.returncode == 0 and "0 of 16 cases failed" in r.stdout, tail + r.stderr[-2000:]

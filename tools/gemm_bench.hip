@@ -82,7 +82,7 @@ struct Builder {
         if (tm == 3300) hipLaunchKernelGGL(gemm_nt_f32x3_kernel, g, dim3(X3_THREADS), 0, st, a);
         else if (tm == 1664) hipLaunchKernelGGL(gemm_nt_bf16w_kernel, g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
-        R16(1) R16(2) R16(4) R16(7) R16(8)
+        R16(1) R16(2) R16(3) R16(4) R16(5) R16(6) R16(7) R16(8)
         else if (tm == 322) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2>), g, b, 0, st, a);
         else if (tm == 321) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 221) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<2, 1, 2, 2>), g, b, 0, st, a);
@@ -239,6 +239,100 @@ __global__ __launch_bounds__(512) void feed_kernel(const float* __restrict__ A, 
     if (acc.x + acc.y + acc.z + acc.w == 1.2345f) out[blockIdx.x * 512 + tid] = acc.x;
 }
 
+
+// ---- fuzz: random ragged grouped launches (1-3 problems, 1-3 k segments each, row gathers, K tails, odd leading dimensions of C,
+// both work decompositions) of the variant under test against an fp64 host reference.  `tools/gemm_bench fuzz <tm> <tn> [cases] [seed]`
+static int fuzz(int tm, int tn, int cases, unsigned seed) {
+    g_bf16 = tm == 1664;
+    const bool wide = tm == 1664 || tm == 3300;           // the 128 x 256 kernels: K multiples of 8 (bf16 chunks)
+    unsigned st = seed * 747796405u + 2891336453u;
+    auto rnd = [&](int lo, int hi) { st = st * 1664525u + 1013904223u; return lo + (int)((st >> 8) % (unsigned)(hi - lo + 1)); };
+    int bad = 0;
+    for (int cs = 0; cs < cases; ++cs) {
+        const int slots = (int[]){8, 64, 256, 256}[rnd(0, 3)];
+        const int aligned = rnd(0, 1);
+        if (aligned) setenv("GEMM_PLAN_ALIGNED", rnd(0, 1) ? "8" : "2", 1); else unsetenv("GEMM_PLAN_ALIGNED");
+        Builder b(slots, rnd(1, 8), tm, tn);
+        const int nprob = rnd(1, 3);
+        struct Host { int M, N, ldc, coff; std::vector<std::vector<float>> A, W; std::vector<int> K, lda, ldw, woff; std::vector<std::vector<int>> idx; float* C; };
+        std::vector<Host> H(nprob);
+        std::vector<void*> to_free;
+        for (int p = 0; p < nprob; ++p) {
+            Host& h = H[p];
+            h.M = rnd(0, 5) == 0 ? rnd(1, 20) : rnd(1, 600);
+            h.N = rnd(0, 5) == 0 ? rnd(1, 40) : rnd(8, 700);
+            h.coff = rnd(0, 1) ? 4 * rnd(0, 3) : rnd(0, 5);
+            h.ldc = h.N + h.coff + (rnd(0, 1) ? 4 * rnd(0, 4) : rnd(0, 7));
+            if (rnd(0, 2)) { h.ldc = (h.ldc + 3) & ~3; h.coff &= ~3; }
+            CK(hipMalloc(&h.C, (size_t)8 * h.M * h.ldc * sizeof(float) + 64)); to_free.push_back(h.C);
+            CK(hipMemset(h.C, 0, (size_t)8 * h.M * h.ldc * sizeof(float) + 64));
+            GemmProb& gp = b.prob(h.M, h.N, h.C + h.coff, h.ldc);
+            const int nseg = rnd(1, 3);
+            for (int sg = 0; sg < nseg; ++sg) {
+                const int q = wide ? 8 : 4;
+                const int K = q * rnd(1, rnd(0, 3) ? 520 / q : 1600 / q);
+                const int rowsA = rnd(0, 1) ? h.M : h.M + rnd(1, 50);
+                const int lda = K + 4 * rnd(0, 3), woff = q * rnd(0, 4), ldw = woff + K + q * rnd(0, 5);
+                float* A = dev_rand((size_t)rowsA * lda, seed * 131 + cs * 17 + p * 5 + sg); to_free.push_back(A);
+                float* W = dev_rand((size_t)h.N * ldw + 64, seed * 137 + cs * 19 + p * 7 + sg); to_free.push_back(W);
+                std::vector<int> idx;
+                int* didx = nullptr;
+                if (rowsA != h.M || rnd(0, 1)) {
+                    idx.resize(h.M);
+                    for (int i = 0; i < h.M; ++i) idx[i] = rnd(0, rowsA - 1);
+                    CK(hipMalloc(&didx, h.M * sizeof(int))); to_free.push_back(didx);
+                    CK(hipMemcpy(didx, idx.data(), h.M * sizeof(int), hipMemcpyHostToDevice));
+                }
+                Builder::seg(gp, A, lda, didx, W + woff, ldw, K);
+                std::vector<float> hA((size_t)rowsA * lda), hW((size_t)h.N * ldw + 64);
+                CK(hipMemcpy(hA.data(), A, hA.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hW.data(), W, hW.size() * 4, hipMemcpyDeviceToHost));
+                h.A.push_back(std::move(hA)); h.W.push_back(std::move(hW)); h.K.push_back(K); h.lda.push_back(lda); h.ldw.push_back(ldw); h.woff.push_back(woff);
+                h.idx.push_back(idx);
+            }
+        }
+        const int ns = b.finish();
+        b.launch(0);
+        CK(hipDeviceSynchronize());
+        double worst = 0, scale = 0;
+        for (int p = 0; p < nprob; ++p) {
+            Host& h = H[p];
+            std::vector<float> hC((size_t)ns * h.M * h.ldc);
+            CK(hipMemcpy(hC.data(), h.C, hC.size() * 4, hipMemcpyDeviceToHost));
+            int ktot = 0; for (int k : h.K) ktot += k;
+            for (int i = 0; i < h.M; ++i)
+                for (int j = 0; j < h.N; ++j) {
+                    double ref = 0;
+                    for (size_t sg = 0; sg < h.K.size(); ++sg) {
+                        const int row = h.idx[sg].empty() ? i : h.idx[sg][i];
+                        const float* a = h.A[sg].data() + (size_t)row * h.lda[sg];
+                        const float* w = h.W[sg].data() + (size_t)j * h.ldw[sg] + h.woff[sg];
+                        for (int k = 0; k < h.K[sg]; ++k) ref += (double)a[k] * w[k];
+                    }
+                    double got = 0;
+                    for (int q = 0; q < ns; ++q) got += hC[(size_t)q * h.M * h.ldc + (size_t)i * h.ldc + h.coff + j];
+                    worst = fmax(worst, fabs(got - ref));
+                }
+            scale = fmax(scale, sqrt((double)ktot) * 0.083);      // |a| |w| ~ U(-0.5, 0.5): products ~ 1/12 rms
+            // the columns of the C window outside [coff, coff + N) must stay untouched (zero)
+            for (int i = 0; i < h.M; ++i)
+                for (int j = 0; j < h.ldc; ++j)
+                    if (j < h.coff || j >= h.coff + h.N)
+                        for (int q = 0; q < ns; ++q)
+                            if (hC[(size_t)q * h.M * h.ldc + (size_t)i * h.ldc + j] != 0.f) { worst = 1e9; }
+        }
+        const double tol = (g_bf16 ? 2e-2 : 2e-5) * fmax(1.0, scale);
+        const bool ok = worst < tol;
+        bad += !ok;
+        printf("fuzz %3d: %d problems (M %d N %d ...), slots %d, %s, G %d nslab %d: max |err| %.3g (tol %.3g) %s\n", cs, nprob, H[0].M, H[0].N, slots,
+               b.a.aligned ? "k-aligned" : "stream-K", b.a.G, ns, worst, tol, ok ? "OK" : "FAIL");
+        for (void* q : to_free) CK(hipFree(q));
+        for (Twin& t : g_twins) if (t.b) CK(hipFree(t.b));
+        g_twins.clear();
+    }
+    printf("fuzz: %d of %d cases failed\n", bad, cases);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "chain")) {
         float* o; CK(hipMalloc(&o, 4096 * 256 * 4));
@@ -258,6 +352,8 @@ int main(int argc, char** argv) {
             }
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "fuzz"))
+        return fuzz(argc > 2 ? atoi(argv[2]) : 1664, argc > 3 ? atoi(argv[3]) : 1, argc > 4 ? atoi(argv[4]) : 40, argc > 5 ? atoi(argv[5]) : 1);
     if (argc > 1 && !strcmp(argv[1], "feed")) {
         const int M = 512, K = 3000, N = 6144, lda = 3000, ldw = 4048;
         float* A = dev_rand((size_t)M * lda, 1); float* Wf = dev_rand((size_t)N * ldw / 2 + 64, 2);

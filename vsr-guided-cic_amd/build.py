@@ -16,6 +16,10 @@ DEPS = [SRC, os.path.join(HERE, "csrc", "gemm_f32.h"), os.path.join(HERE, "csrc"
         os.path.join(HERE, "csrc", "cider.inc.h"),
         os.path.join(os.path.dirname(HERE), "include", "vsrcap.h")]
 OUT = os.path.join(HERE, "vsrcap", "libvsrcap.so")
+# standalone GEMM check / timing tool (tools/README.md); its `fuzz` mode is run by tests/test_gpu_gemm_fuzz.py
+TOOL_SRC = os.path.join(os.path.dirname(HERE), "tools", "gemm_bench.hip")
+TOOL_DEPS = [TOOL_SRC, os.path.join(os.path.dirname(HERE), "tools", "gemm_bf16x3.h"), os.path.join(os.path.dirname(HERE), "tools", "gemm_dma_variant.h")] + DEPS[1:4]
+TOOL_OUT = os.path.join(os.path.dirname(HERE), "tools", "gemm_bench")
 
 
 def needs_build():
@@ -38,5 +42,16 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_tool(force=False):
+    if not force and os.path.exists(TOOL_OUT) and all(not os.path.exists(d) or os.path.getmtime(d) <= os.path.getmtime(TOOL_OUT) for d in TOOL_DEPS):
+        return TOOL_OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-o", TOOL_OUT + ".tmp", TOOL_SRC], check=True)
+    os.replace(TOOL_OUT + ".tmp", TOOL_OUT)
+    return TOOL_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))
+    if "--tool" in sys.argv:
+        print(build_tool(force="--force" in sys.argv))
