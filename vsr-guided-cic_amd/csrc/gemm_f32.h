@@ -67,6 +67,18 @@ struct GemmArgs {
     unsigned long long* dbg;   // diagnostics build only (GEMM_STAMP): per-workgroup {shader cycles, 100 MHz ticks}
 };
 
+// tile index -> tile origin.  GEMM_TILE_ORDER 0: m fastest (the m-tiles of a weight n-tile are neighbours), 1: n fastest
+#ifndef GEMM_TILE_ORDER
+#define GEMM_TILE_ORDER 0
+#endif
+__device__ __forceinline__ void gemm_tile_origin(const GemmProb& P, int tile, int BM, int BN, int& m0, int& n0) {
+#if GEMM_TILE_ORDER == 1
+    m0 = (tile / P.tiles_n) * BM; n0 = (tile % P.tiles_n) * BN;
+#else
+    m0 = (tile % P.tiles_m) * BM; n0 = (tile / P.tiles_m) * BN;
+#endif
+}
+
 #ifndef GEMM_ABLATE
 #define GEMM_ABLATE 0    // diagnostics only (tools/gemm_bench.hip): 1 = no global loads in the loop, 2 = also no LDS refill
 #endif
@@ -148,7 +160,8 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
     auto open_segment = [&](int s, int first_tile) __attribute__((always_inline)) {
         const GemmProb& P = args.p[l_prob];
         const GemmSeg& S = P.seg[s];
-        const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
+        int m0, n0;
+        gemm_tile_origin(P, l_tile, BM, BN, m0, n0);
         l_seg = s;
         l_K = S.K;
         l_k = first_tile * GEMM_BK;
@@ -245,7 +258,8 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
     constexpr int ST_LD = BN + 4;
     auto flush = [&](const f32x16 (&acc)[TM][TN], float* stage) __attribute__((always_inline)) {
         const GemmProb& P = args.p[c_prob];
-        const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
+        int m0, n0;
+        gemm_tile_origin(P, c_tile, BM, BN, m0, n0);
         float* C = P.C + (long long)c_piece * P.slab_stride;
         const int extra = c_last ? args.nslab - 1 - c_piece : 0;     // unused slabs of a finished tile: zeros
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
