@@ -634,6 +634,7 @@ __device__ __forceinline__ void gatelogit_block(const GateLogitArgs& g, int row,
     float s = 0.f;
     for (int a = tid; a < g.A; a += NT) {
         const float x = slab_sum(g.ga + (long long)row * g.A + a, g.nsplit, g.stride);
+        if (g.ga_out) g.ga_out[(long long)row * g.A + a] = x;
         s += g.w_g[a] * tanhf(x + g.hA[(long long)row * g.A + a]);
     }
     s = wave_sum(s);

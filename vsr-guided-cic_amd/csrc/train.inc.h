@@ -273,7 +273,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
             GateLogitArgs gl{gas, ns, stride_g, hA, w.att_g_weight, c.zsum, nullptr, slot, 1, c.L, B, A,
                              logp_gates + (size_t)tt * 2, (long long)T * 2};
             gl.ga_out = ga;
-            const int gblocks = cdiv(B, 4);
+            const int gblocks = B;
             hipLaunchKernelGGL(k_fwd_tail, dim3(gblocks + cdiv((long long)B * H, 256)), dim3(256), 0, s, gl, gblocks, c.scratch, ns, stride,
                                w.lstm2_bias_ih, w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, c2o, B, H, h2n, c2n, g2);
         }

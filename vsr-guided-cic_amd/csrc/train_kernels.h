@@ -180,15 +180,15 @@ __global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long lo
     gates[base] = ig; gates[base + H] = fg; gates[base + 2LL * H] = gg; gates[base + 3LL * H] = og; gates[base + 4LL * H] = sg;
 }
 
-// after the S5 GEMM, one launch: blocks [0, gblocks) finish att_ga(g_t) from its slabs (saved for the backward pass) and
-// write the step's gate log-probs, one wave per row; the other blocks are LSTM2 with its post-activation gates saved
+// after the S5 GEMM, one launch: blocks [0, gblocks = M) finish att_ga(g_t) from its slabs (saved for the backward pass) and
+// write the step's gate log-probs, one workgroup per row; the other blocks are LSTM2 with its post-activation gates saved
 __global__ __launch_bounds__(256) void k_fwd_tail(const GateLogitArgs gl, int gblocks,
                                                   const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ b_ih,
                                                   const float* __restrict__ b_hh, const float* __restrict__ vproj2, const float* __restrict__ c2_old,
                                                   int M, int H, float* __restrict__ h2n, float* __restrict__ c2n, float* __restrict__ gates) {
-    if ((int)blockIdx.x < gblocks) {
-        const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (row < gl.M) gatelogit_row(gl, row, threadIdx.x & 63);
+    if ((int)blockIdx.x < gblocks) {                      // one workgroup per row: every slab of a column in flight at once (a wave
+        __shared__ float red[4];                          // per row walked the slabs in dependent rounds: 20 us at 8 slabs)
+        gatelogit_block<256>(gl, blockIdx.x, red);
         return;
     }
     const long long i = (long long)(blockIdx.x - gblocks) * 256 + threadIdx.x;
