@@ -580,54 +580,9 @@ struct GateLogitArgs {
     float* ga_out = nullptr;                             // optional (M, A): the slab sums (the training forward saves them)
 };
 
-// one wave per row
-__device__ __forceinline__ void gatelogit_row(const GateLogitArgs& g, int row, int lane) {
-    float s = 0.f;
-    // eight columns per lane and round, every slab of every column loaded before the first tanh (the row is one wave's
-    // latency chain: A / 64 dependent rounds otherwise)
-    for (int a0 = lane; a0 < g.A; a0 += 64 * 8) {
-        float x[8], h[8], wv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int a = a0 + 64 * q;
-            const bool in = a < g.A;
-            h[q] = in ? g.hA[(long long)row * g.A + a] : 0.f;
-            wv[q] = in ? g.w_g[a] : 0.f;
-            x[q] = 0.f;
-        }
-        for (int k = 0; k < g.nsplit; ++k) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int a = a0 + 64 * q;
-                if (a < g.A) x[q] += g.ga[k * g.stride + (long long)row * g.A + a];
-            }
-        }
-        if (g.ga_out) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (a0 + 64 * q < g.A) g.ga_out[(long long)row * g.A + a0 + 64 * q] = x[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (a0 + 64 * q < g.A) s += wv[q] * tanhf(x[q] + h[q]);
-    }
-    s = wave_sum(s);
-    if (lane == 0) {
-        const float a = s, b = g.zsum[row];
-        const float mx = fmaxf(a, b);
-        const float lse = mx + logf(expf(a - mx) + expf(b - mx));
-        float l0 = a - lse, l1 = b - lse;
-        if (g.verbs) {
-            const float v = g.verbs[(long long)(row / g.rpi) * g.L + g.slot[row]];
-            if (v != -1.f) { l0 = -1e3f; l1 = 0.f; }
-        }
-        g.lg[(long long)row * g.lg_stride] = l0;
-        g.lg[(long long)row * g.lg_stride + 1] = l1;
-    }
-}
-
-// the same row by a whole workgroup (the vocabulary kernel's blocks do their row's gate logits on the side): one column
-// per thread, wave sums combined in wave order
+// one row by a whole workgroup (the vocabulary kernel's blocks do their row's gate logits on the side; k_fwd_tail of the
+// training forward gives every row a workgroup): one column per thread, every slab of it in flight at once, wave sums
+// combined in wave order
 template <int NT>
 __device__ __forceinline__ void gatelogit_block(const GateLogitArgs& g, int row, float* red /* NT / 64 floats of LDS */) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
