@@ -118,3 +118,23 @@ def test_bf16_k_aligned_plan_equals_stream_k_plan(monkeypatch):
     assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-3
     assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-3
     assert torch.equal(toks[0][:, :5], toks[1][:, :5])
+
+
+def test_bf16_producer_written_a_images_change_nothing(monkeypatch):
+    """bf16 mode, decode: the producers of the GEMMs' A operands (k_lstm1, k_attend, k_lstm2) write a bf16 image next to the fp32
+    value and the GEMM loads that image instead of converting the fp32 rows itself (VSR_BF16_A16=0: off).  Same rounding of the same
+    values: tokens, gates and scores must be IDENTICAL with and without, for greedy and beam search."""
+    meta, _ = load_golden("g2_greedy")
+    det, ctrl = helpers.decode_inputs(meta["cfg"], meta["seed"], n=48)
+    det, ctrl = det.to(DEV), ctrl.to(DEV)
+    res = []
+    for a16 in ("1", "0"):
+        monkeypatch.setenv("VSR_BF16_A16", a16)
+        m = _model(meta)                                  # a fresh model -> a fresh handle that reads the environment
+        m.set_compute_dtype("bf16")
+        with torch.no_grad():
+            w, g = m.test(det, ctrl)
+            (bw, bg), (lw, lg) = m.beam_search((det, ctrl), meta["eos"], 5, 1)
+        res.append((w.cpu(), g.cpu(), bw.cpu(), bg.cpu(), lw.cpu(), lg.cpu()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

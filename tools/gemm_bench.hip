@@ -80,7 +80,7 @@ struct Builder {
 #define R16(TM_) else if (tm == 1600 + TM_ && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 2>), g, dim3(512), 0, st, a); \
                  else if (tm == 1600 + TM_ && tn == 4) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 4>), g, dim3(512), 0, st, a);
         if (tm == 3300) hipLaunchKernelGGL(gemm_nt_f32x3_kernel, g, dim3(X3_THREADS), 0, st, a);
-        else if (tm == 1664) hipLaunchKernelGGL(gemm_nt_bf16w_kernel, g, dim3(B16_THREADS), 0, st, a);
+        else if (tm == 1664) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<false>, g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
         R16(1) R16(2) R16(3) R16(4) R16(5) R16(6) R16(7) R16(8)
         else if (tm == 322) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2>), g, b, 0, st, a);

@@ -76,7 +76,10 @@ __device__ __forceinline__ void landed(u32x4_t& d) { asm volatile("" : "+v"(d));
 // at ISSUE - with one kind of wave the 1.26 us of feed, the 0.5 us LDS refill and the 1.1 us of ds_read + MFMA therefore add up
 // (2.7 us per k-tile, measured with one, two and three tiles in flight alike).  The movers take the stall, the multipliers keep
 // the matrix pipe busy; they meet at ONE barrier per k-tile, which then costs max(feed + refill, multiply).
+// A16K: every segment's A operand comes with a bf16 image (GemmSeg::A16, written by A's producer): the movers load 8 bf16 per
+// lane and store them as they are - half the A bytes, no conversion.  Otherwise A is fp32 and converted on the way into LDS.
 constexpr int B16_THREADS = 1024;
+template <bool A16K>
 __global__ __launch_bounds__(B16_THREADS)
 void gemm_nt_bf16w_kernel(const GemmArgs args) {
     constexpr int WN = 4, TM = 2, TN = 2;                  // multipliers: 2 x 4 waves, wave tile 64 x 64
@@ -207,10 +210,15 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
         const int ptid = tid - 512;
         const int arow = ptid >> 4, ak = (ptid & 15) * 4;  // A: 16 lanes per row, 4 fp32 each (whole 128-byte lines per wave instruction)
         const int brow = ptid >> 3, bk = (ptid & 7) * 8;   // W: 8 lanes per row, 8 bf16 each
-        f32x4_t ra[2][LA];                                 // tile j (counted from it0) lives in register set j & 1
+        // A pieces per thread and tile: fp32 - LA loads of 4 floats (16 lanes per row, converted on the way into LDS); bf16 image -
+        // LA / 2 loads of 8 bf16 (8 lanes per row, stored as they are)
+        constexpr int NA = A16K ? LA / 2 : LA;
+        const int arow16 = ptid >> 3, ak16 = (ptid & 7) * 8;
+        f32x4_t ra[2][NA];                                 // tile j (counted from it0) lives in register set j & 1
         u32x4_t rb[2][LB];
         bool sta[2] = {false, false}, stb[2] = {false, false};
-        const float* pa[LA];
+        const float* pa[NA];
+        const uint16_t* pa16[NA];
         const uint16_t* pb[LB];
         int l_prob = 0, l_tile = 0, l_tile_left = 0;
         int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;
@@ -222,12 +230,22 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
             l_K = S.K;
             l_k = first_tile * BK;
             l_seg_left = (S.K + BK - 1) / BK - first_tile;
+            if constexpr (A16K) {
 #pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                int m = m0 + arow + 32 * i;
-                m = m < P.M ? m : P.M - 1;
-                const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
-                pa[i] = S.A + row * S.lda + ak;
+                for (int i = 0; i < NA; ++i) {
+                    int m = m0 + arow16 + 64 * i;
+                    m = m < P.M ? m : P.M - 1;
+                    const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
+                    pa16[i] = S.A16 + row * S.lda + ak16;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    int m = m0 + arow + 32 * i;
+                    m = m < P.M ? m : P.M - 1;
+                    const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
+                    pa[i] = S.A + row * S.lda + ak;
+                }
             }
 #pragma unroll
             for (int i = 0; i < LB; ++i) {
@@ -254,7 +272,7 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
             } else if (l_seg_left == 0) {
                 open_segment(l_seg + 1, 0);
             }
-            ta = !(l_k + ak < l_K);                        // K is a multiple of 8: a piece is inside or outside as a whole
+            ta = !(l_k + (A16K ? ak16 : ak) < l_K);        // K is a multiple of 8: a piece is inside or outside as a whole
             tb = !(l_k + bk < l_K);
             ka = ta ? 0 : l_k;
             kb = tb ? 0 : l_k;
@@ -266,8 +284,13 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
         auto issue = [&](auto S) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
             advance();
+            if constexpr (A16K) {
 #pragma unroll
-            for (int i = 0; i < LA; ++i) async_load16(ra[s][i], pa[i] + ka);
+                for (int i = 0; i < NA; ++i) async_load16(ra[s][i], pa16[i] + ka);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) async_load16(ra[s][i], pa[i] + ka);
+            }
 #pragma unroll
             for (int i = 0; i < LB; ++i) async_load16(rb[s][i], pb[i] + kb);
             sta[s] = ta; stb[s] = tb;
@@ -275,20 +298,29 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
         // set S has landed once at most the loads of the other (younger) set are still in flight
         auto landed_set = [&](auto S, bool other_in_flight) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
-            if (other_in_flight) wait_loads<LA + LB>(); else wait_loads<0>();
+            if (other_in_flight) wait_loads<NA + LB>(); else wait_loads<0>();
 #pragma unroll
-            for (int i = 0; i < LA; ++i) landed(ra[s][i]);
+            for (int i = 0; i < NA; ++i) landed(ra[s][i]);
 #pragma unroll
             for (int i = 0; i < LB; ++i) landed(rb[s][i]);
         };
         auto store_tile = [&](auto S, int buf) __attribute__((always_inline)) {
             constexpr int s = decltype(S)::value;
+            if constexpr (A16K) {
 #pragma unroll
-            for (int i = 0; i < LA; ++i) {
-                uint2 o;
-                o.x = pack_bf16(ra[s][i].x, ra[s][i].y); o.y = pack_bf16(ra[s][i].z, ra[s][i].w);
-                if (sta[s]) o = make_uint2(0u, 0u);
-                *reinterpret_cast<uint2*>(sA(buf) + (arow + 32 * i) * B16_ROW + ak) = o;
+                for (int i = 0; i < NA; ++i) {
+                    uint4 o = make_uint4(__float_as_uint(ra[s][i].x), __float_as_uint(ra[s][i].y), __float_as_uint(ra[s][i].z), __float_as_uint(ra[s][i].w));
+                    if (sta[s]) o = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(sA(buf) + (arow16 + 64 * i) * B16_ROW + ak16) = o;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    uint2 o;
+                    o.x = pack_bf16(ra[s][i].x, ra[s][i].y); o.y = pack_bf16(ra[s][i].z, ra[s][i].w);
+                    if (sta[s]) o = make_uint2(0u, 0u);
+                    *reinterpret_cast<uint2*>(sA(buf) + (arow + 32 * i) * B16_ROW + ak) = o;
+                }
             }
 #pragma unroll
             for (int i = 0; i < LB; ++i) {

@@ -39,6 +39,7 @@ struct GemmSeg {
     int ldw;
     int K;               // multiple of 4
     int pad_;
+    const uint16_t* A16; // bf16 kernel only, optional: a bf16 image of A (same rows, same lda) written by A's producer
 };
 
 struct GemmProb {

@@ -26,6 +26,21 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ p, int nslab
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// bf16 image (round-to-nearest-even) of a value / of four consecutive values: the bf16 GEMM mode lets the producers of its A
+// operands write this image next to the fp32 value, so that the GEMM loads half the bytes and converts nothing
+__device__ __forceinline__ uint16_t bf16_bits(float x) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {x, 0.f};
+    return (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2)) & 0xffffu);
+}
+__device__ __forceinline__ uint2 bf16_bits4(float4 v) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    return make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, b2)), __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, b2)));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -254,7 +269,8 @@ __global__ void k_i32_to_i64(const int* src, int64_t* dst, int n) {
 __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ vproj,
                         int rpi, const int* __restrict__ parent, const float* __restrict__ c1_old, int M, int H,
                         float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre,
-                        const float* __restrict__ xproj, const int* __restrict__ word, int nblk, int pre_by_parent) {
+                        const float* __restrict__ xproj, const int* __restrict__ word, int nblk, int pre_by_parent,
+                        uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16 /* optional bf16 images (bf16 GEMM mode) */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
@@ -274,10 +290,12 @@ __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long str
     const float c_old = c1_old[(long long)prow * H + j];
     const float c = sigmoidf_(q[1]) * c_old + sigmoidf_(q[0]) * tanhf(q[2]);
     const float tc = tanhf(c);
-    h1n[i] = sigmoidf_(q[3]) * tc;
+    const float h1v = sigmoidf_(q[3]) * tc, stv = sigmoidf_(q[4]) * tc;
+    h1n[i] = h1v;
     c1n[i] = c;
-    s_t[i] = sigmoidf_(q[4]) * tc;
+    s_t[i] = stv;
     gpre[i] = q[5];
+    if (h1n16) { h1n16[i] = bf16_bits(h1v); s_t16[i] = bf16_bits(stv); }
 }
 
 // reduce the slabs of h1 -> [W1_hg | att_ha] and s_t -> [s_fc | att_sa]; finish the shift-gate vector
@@ -322,6 +340,7 @@ struct Gate2Args {
     const float* c2a; const float* c2b; int nsplit; long long stride_a, stride_b;
     const float* gpre; const float* c1n; const float* b_sfc; int H;
     float* g_t; float* hA_out;
+    uint16_t* g_t16 = nullptr;      // optional bf16 image of g_t (bf16 GEMM mode)
 };
 
 #ifndef ATT_ABLATE
@@ -335,7 +354,8 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                                                 const int* __restrict__ slot, int fixed_slot, int rpi, int M, int L,
                                                 int R, int A, int D, const float* __restrict__ w_a,
                                                 const float* __restrict__ w_s, float* __restrict__ att,
-                                                float* __restrict__ zsum, float* __restrict__ alpha_out) {
+                                                float* __restrict__ zsum, float* __restrict__ alpha_out,
+                                                uint16_t* __restrict__ att16 = nullptr /* optional bf16 image of att */) {
     extern __shared__ float sm[];
     float* hA_s = sm;             // A
     float* sa_s = hA_s + A;       // A   (fused gate2 only)
@@ -380,6 +400,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                     o.x = sigmoidf_(gp.x + s.x) * tanhf(cn.x); o.y = sigmoidf_(gp.y + s.y) * tanhf(cn.y);
                     o.z = sigmoidf_(gp.z + s.z) * tanhf(cn.z); o.w = sigmoidf_(gp.w + s.w) * tanhf(cn.w);
                     *reinterpret_cast<float4*>(g2.g_t + (long long)row * H + c) = o;
+                    if (g2.g_t16) *reinterpret_cast<uint2*>(g2.g_t16 + (long long)row * H + c) = bf16_bits4(o);
                 } else {
                     *reinterpret_cast<float4*>(hA_s + (c - H)) = s;
                     *reinterpret_cast<float4*>(g2.hA_out + (long long)row * A + (c - H)) = s;
@@ -406,7 +427,9 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
             for (int c = tid; c < H + A; c += NT) {
                 const float s = slab_sum(g2.c2a + (long long)row * (H + A) + c, g2.nsplit, g2.stride_a);
                 if (c < H) {
-                    g2.g_t[(long long)row * H + c] = sigmoidf_(g2.gpre[(long long)row * H + c] + s) * tanhf(g2.c1n[(long long)row * H + c]);
+                    const float gv = sigmoidf_(g2.gpre[(long long)row * H + c] + s) * tanhf(g2.c1n[(long long)row * H + c]);
+                    g2.g_t[(long long)row * H + c] = gv;
+                    if (g2.g_t16) g2.g_t16[(long long)row * H + c] = bf16_bits(gv);
                 } else {
                     hA_s[c - H] = s;
                     g2.hA_out[(long long)row * A + (c - H)] = s;
@@ -544,6 +567,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
             }
         }
         *reinterpret_cast<float4*>(att + (long long)row * D + d) = acc;
+        if (att16) *reinterpret_cast<uint2*>(att16 + (long long)row * D + d) = bf16_bits4(acc);
     }
 }
 
@@ -551,7 +575,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
 __global__ void k_lstm2(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ b_ih,
                         const float* __restrict__ b_hh, const float* __restrict__ vproj2, int rpi,
                         const int* __restrict__ parent, const float* __restrict__ c2_old, int M, int H,
-                        float* __restrict__ h2n, float* __restrict__ c2n) {
+                        float* __restrict__ h2n, float* __restrict__ c2n, uint16_t* __restrict__ h2n16 = nullptr /* optional bf16 image */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
@@ -566,8 +590,10 @@ __global__ void k_lstm2(const float* __restrict__ pre, int nsplit, long long str
     }
     const int prow = parent ? parent[row] : row;
     const float c = sigmoidf_(q[1]) * c2_old[(long long)prow * H + j] + sigmoidf_(q[0]) * tanhf(q[2]);
-    h2n[i] = sigmoidf_(q[3]) * tanhf(c);
+    const float h2v = sigmoidf_(q[3]) * tanhf(c);
+    h2n[i] = h2v;
     c2n[i] = c;
+    if (h2n16) h2n16[i] = bf16_bits(h2v);
 }
 
 // shift-gate log-probabilities: z_g = w_g . tanh(att_ga g_t + hA); gate = log_softmax([z_g, zsum])   (:184-188)

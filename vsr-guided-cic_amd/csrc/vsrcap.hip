@@ -72,6 +72,11 @@ struct Ctx {
     int64_t* tmp_i64;
     float* scratch;
     size_t scratch_floats = 0;
+    // bf16 GEMM mode: bf16 images of the GEMMs' A operands, written by their producers next to the fp32 values (h1, h2 of both
+    // state buffers, s_t, g_t, att); st16_ok[i]: the images of state buffer i match its fp32 content
+    uint16_t* st16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    uint16_t *s_t16 = nullptr, *g_t16 = nullptr, *att16 = nullptr;
+    bool st16_ok[2] = {false, false};
     float* pre1 = nullptr;       // LSTM1/gate sums of the NEXT step, produced early (merged with the vocabulary GEMM)
     int pre1_ns = 0, pre1_nblk = 0;
     long long pre1_stride = 0;
@@ -115,6 +120,7 @@ struct vsr_handle {
     // shard of 12-13 images and its 65 beam rows, small eval batches) the 64-row tiles are mostly padding and the rows-16 kernel wins
     // (M = 13: 19.5 vs 13.2 TF/s over the four step GEMMs; beam-5 over a 13-image shard, M = 65: 3.48 vs 3.81 ms per call).
     int gemm_r16_max = 80;
+    int bf16_a16 = 1;            // bf16 mode: the decode step's producers write bf16 images of the GEMM A operands (VSR_BF16_A16=0: off)
     int gemm_aligned = 1;        // 128 x 256 kernels: k-aligned pieces (gemm_plan_aligned) when the tiles fit the CUs; VSR_GEMM_ALIGNED=0: stream-K always
     int gemm_aligned_min = 8;    // shortest piece, in 64-wide k-tiles (VSR_GEMM_ALIGNED_MIN)
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
@@ -203,6 +209,12 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     c.scratch_floats = std::max(stage * 8, std::max(rows, prows) * A * 8);   // att_va slabs of prepare(): over the bank rows when indexed
     c.scratch = b.take<float>(c.scratch_floats);
     c.pre1 = b.take<float>(M * 6 * H * 8);
+    b.off = (b.off + 15) & ~size_t(15);
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) c.st16[i][j] = b.take<uint16_t>((M * H + 7) & ~size_t(7));
+    c.s_t16 = b.take<uint16_t>((M * H + 7) & ~size_t(7));
+    c.g_t16 = b.take<uint16_t>((M * H + 7) & ~size_t(7));
+    c.att16 = b.take<uint16_t>((M * D + 7) & ~size_t(7));
     return (b.off + 255) & ~size_t(255);
 }
 
@@ -215,13 +227,14 @@ struct GemmBuilder {
         p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.nseg = 0;
         return p;
     }
-    static void seg(GemmProb& p, const float* A, int lda, const int* idx, const float* W, int ldw, int K) {
+    static void seg(GemmProb& p, const float* A, int lda, const int* idx, const float* W, int ldw, int K, const uint16_t* A16 = nullptr) {
         if (K <= 0) return;
         GemmSeg& s = p.seg[p.nseg++];
-        s.A = A; s.lda = lda; s.a_idx = idx; s.W = W; s.ldw = ldw; s.K = K;
+        s.A = A; s.lda = lda; s.a_idx = idx; s.W = W; s.ldw = ldw; s.K = K; s.A16 = A16;
     }
     int big = 0;       // 2: 128x128 workgroup tiles, 1: 128x64, 0: 64x64 (32x32x2 MFMA); 16: rows-16 kernel (16x16x4 MFMA), r16_tm tiles
     int r16_tm = 0;
+    bool a16_all = false;   // bf16 kernel: every segment's A operand has a bf16 image (GemmSeg::A16)
     // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
     int finish(const vsr_handle* h) {
         int maxM = 0;
@@ -238,8 +251,13 @@ struct GemmBuilder {
                          ((reinterpret_cast<uintptr_t>(S.A) & 15) == 0);
                 }
             if (ok) {
+                a16_all = true;
                 for (int i = 0; i < a.nprob; ++i)
-                    for (int sg = 0; sg < a.p[i].nseg; ++sg) a.p[i].seg[sg].W = reinterpret_cast<const float*>(h->map16(a.p[i].seg[sg].W));
+                    for (int sg = 0; sg < a.p[i].nseg; ++sg) {
+                        GemmSeg& S = a.p[i].seg[sg];
+                        S.W = reinterpret_cast<const float*>(h->map16(S.W));
+                        a16_all = a16_all && S.A16 && (S.lda % 8 == 0) && ((reinterpret_cast<uintptr_t>(S.A16) & 15) == 0);
+                    }
                 big = 32;
                 if (h->gemm_aligned)
                     if (const int ns = gemm_plan_aligned(a, h->gemm_slots_bf16, h->gemm_aligned_min, 128, 256, B16_BK)) return ns;
@@ -281,7 +299,8 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
     if (big == 33) hipLaunchKernelGGL(gemm_nt_f32x3_kernel, grid, block, 0, s, a);
-    else if (big == 32) hipLaunchKernelGGL(gemm_nt_bf16w_kernel, grid, block, 0, s, a);
+    else if (big == 32 && a16_all) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<true>, grid, block, 0, s, a);
+    else if (big == 32) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<false>, grid, block, 0, s, a);
     else if (big == 16) {
         switch (r16_tm) {
             case 1: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<1, 2>), grid, block, 0, s, a); break;
@@ -338,6 +357,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_GEMM_SLOTS_R16")) h->gemm_slots_r16 = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_R16_MAX")) h->gemm_r16_max = atoi(e);
     if (const char* e = getenv("VSR_GEMM_ALIGNED")) h->gemm_aligned = atoi(e);
+    if (const char* e = getenv("VSR_BF16_A16")) h->bf16_a16 = atoi(e);
     if (const char* e = getenv("VSR_GEMM_ALIGNED_MIN")) h->gemm_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS")) h->gemm_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_SMALL")) h->gemm_slots_small = std::max(1, atoi(e));
@@ -711,11 +731,17 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     float* const* sn = c.st[io.cur ^ 1];      // new state
     float *h1o = so[0], *c1o = so[1], *h2o = so[2], *c2o = so[3];
     float *h1n = sn[0], *c1n = sn[1], *h2n = sn[2], *c2n = sn[3];
+    // bf16 images of the A operands (bf16 mode): the producers below write them, the GEMM segments name them
+    const bool sh = h->bf16_on && h->bf16_a16;
+    const bool sh_old = sh && c.st16_ok[io.cur];
+    uint16_t *h1n16 = sh ? c.st16[io.cur ^ 1][0] : nullptr, *h2n16 = sh ? c.st16[io.cur ^ 1][1] : nullptr;
+    const uint16_t *h1o16 = sh_old ? c.st16[io.cur][0] : nullptr, *h2o16 = sh_old ? c.st16[io.cur][1] : nullptr;
+    uint16_t *s_t16 = sh ? c.s_t16 : nullptr, *g_t16 = sh ? c.g_t16 : nullptr, *att16 = sh ? c.att16 : nullptr;
 
     // ---- S1
     if (io.s1_from_prev) {
         hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.pre1, c.pre1_ns, c.pre1_stride, c.vproj, io.rpi,
-                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, c.pre1_nblk, 1);
+                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, c.pre1_nblk, 1, h1n16, s_t16);
     } else {
         const bool xc = h->xproj != nullptr;            // embedding part comes from the decode cache
         GemmBuilder g;
@@ -728,9 +754,9 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
             const bool has_h2 = d.h2_first_lstm && io.t > 0, has_x = !xc, has_h1 = Whh[i] && io.t > 0;
             if (!has_h2 && !has_x && !has_h1) continue;
             GemmProb& p = g.prob(M, Nn[i], c.scratch + off[i], 6 * H);
-            if (has_h2) GemmBuilder::seg(p, h2o, H, io.parent, Wih[i], in1, H);
+            if (has_h2) GemmBuilder::seg(p, h2o, H, io.parent, Wih[i], in1, H, h2o16);
             if (has_x) GemmBuilder::seg(p, w.embed_weight, E, io.word_prev, Wih[i] + xoff, in1, E);
-            if (has_h1) GemmBuilder::seg(p, h1o, H, io.parent, Whh[i], H, H);
+            if (has_h1) GemmBuilder::seg(p, h1o, H, io.parent, Whh[i], H, H, h1o16);
             nblk = i == 0 ? 4 : i == 1 ? 5 : 6;
         }
         int ns = 0;
@@ -741,7 +767,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
             if (g.launch(s, h)) return fail("S1 gemm launch failed");
         }
         hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj, io.rpi,
-                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, nblk, 0);
+                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, nblk, 0, h1n16, s_t16);
     }
     // ---- S2
     {
@@ -749,13 +775,13 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         float* c2a = c.scratch;
         float* c2b_base;
         GemmProb& p0 = g.prob(M, H, c2a, H + A);
-        GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H);
+        GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H, h1n16);
         GemmProb& p1 = g.prob(M, A, c2a + H, H + A);
-        GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H);
+        GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H, h1n16);
         GemmProb& p2 = g.prob(M, D, nullptr, D + A);
-        GemmBuilder::seg(p2, c.s_t, H, nullptr, w.s_fc_weight, H, H);
+        GemmBuilder::seg(p2, c.s_t, H, nullptr, w.s_fc_weight, H, H, s_t16);
         GemmProb& p3 = g.prob(M, A, nullptr, D + A);
-        GemmBuilder::seg(p3, c.s_t, H, nullptr, w.att_sa_weight, H, H);
+        GemmBuilder::seg(p3, c.s_t, H, nullptr, w.att_sa_weight, H, H, s_t16);
         const int ns = g.finish(h);
         const long long stride_a = (long long)M * (H + A), stride_b = (long long)M * (D + A);
         c2b_base = c2a + stride_a * ns;
@@ -764,30 +790,30 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[2].slab_stride = g.a.p[3].slab_stride = stride_b;
         if (g.launch(s, h)) return fail("S2 gemm launch failed");
         // k_gate2's work (g_t, hA, s_a, sentinel from the S2 slabs) is done by the attention kernel's row blocks themselves
-        const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA};
+        const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16};
         const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
         if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out);
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16);
         else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out);
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16);
     }
     // ---- S5
     GateLogitArgs gate_args;
     {
         GemmBuilder g;
         GemmProb& p0 = g.prob(M, 4 * H, c.scratch, 4 * H);
-        GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H);
-        GemmBuilder::seg(p0, c.att, D, nullptr, w.lstm2_weight_ih + H, in2, D);
-        if (io.t > 0) GemmBuilder::seg(p0, h2o, H, io.parent, w.lstm2_weight_hh, H, H);
+        GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H, h1n16);
+        GemmBuilder::seg(p0, c.att, D, nullptr, w.lstm2_weight_ih + H, in2, D, att16);
+        if (io.t > 0) GemmBuilder::seg(p0, h2o, H, io.parent, w.lstm2_weight_hh, H, H, h2o16);
         GemmProb& p1 = g.prob(M, A, nullptr, A);
-        GemmBuilder::seg(p1, c.g_t, H, nullptr, w.att_ga_weight, H, H);
+        GemmBuilder::seg(p1, c.g_t, H, nullptr, w.att_ga_weight, H, H, g_t16);
         const int ns = g.finish(h);
         const long long stride = (long long)M * 4 * H, stride_g = (long long)M * A;
         g.a.p[0].slab_stride = stride;
         g.a.p[1].C = c.ga_slabs; g.a.p[1].slab_stride = stride_g;
         if (g.launch(s, h)) return fail("S5 gemm launch failed");
         hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
-                           w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n);
+                           w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n, h2n16);
         // the gate logits (z_g, log_softmax([z_g, zsum]), step :185-188) are nobody's input before the selection: the
         // vocabulary kernel's row blocks compute them on the side instead of a launch of their own
         gate_args = GateLogitArgs{c.ga_slabs, ns, stride_g, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A,
@@ -797,7 +823,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     {
         GemmBuilder g;
         GemmProb& p0 = g.prob(M, V, c.scratch, V);
-        GemmBuilder::seg(p0, h2n, H, nullptr, w.out_fc_weight, H, H);
+        GemmBuilder::seg(p0, h2n, H, nullptr, w.out_fc_weight, H, H, h2n16);
         int nblk = 0;
         if (io.s1_for_next) {
             // LSTM1 / gate sums of step t+1 over THIS step's rows: they depend on (h2, h1) only (the word enters through the
@@ -809,8 +835,8 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
             for (int i = 0; i < 3; ++i) {
                 if (!d.h2_first_lstm && !Whh[i]) continue;
                 GemmProb& p = g.prob(M, Nn[i], c.pre1 + off[i], 6 * H);
-                if (d.h2_first_lstm) GemmBuilder::seg(p, h2n, H, nullptr, Wih[i], in1, H);
-                if (Whh[i]) GemmBuilder::seg(p, h1n, H, nullptr, Whh[i], H, H);
+                if (d.h2_first_lstm) GemmBuilder::seg(p, h2n, H, nullptr, Wih[i], in1, H, h2n16);
+                if (Whh[i]) GemmBuilder::seg(p, h1n, H, nullptr, Whh[i], H, H, h1n16);
                 nblk = i == 0 ? 4 : i == 1 ? 5 : 6;
             }
         }
@@ -842,6 +868,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
 #undef VOCAB_LAUNCH
 #undef VOCAB_ARGS
     }
+    c.st16_ok[io.cur ^ 1] = sh;               // the new state's bf16 images exist iff this step wrote them
     LAUNCHCHK();
     return 0;
 }
@@ -858,6 +885,10 @@ static int zero_state(vsr_handle* h, int M, hipStream_t s) {
     const size_t n = (size_t)M * h->d.rnn_size * sizeof(float);
     // the four state arrays of buffer 0 are consecutive in the workspace (carve): one memset
     HIPCHK(hipMemsetAsync(c.st[0][0], 0, (size_t)(reinterpret_cast<char*>(c.st[0][3]) - reinterpret_cast<char*>(c.st[0][0])) + n, s));
+    HIPCHK(hipMemsetAsync(c.st16[0][0], 0, (size_t)M * h->d.rnn_size * sizeof(uint16_t), s));     // bf16 images of the zero h1 / h2
+    HIPCHK(hipMemsetAsync(c.st16[0][1], 0, (size_t)M * h->d.rnn_size * sizeof(uint16_t), s));
+    c.st16_ok[0] = true;
+    c.st16_ok[1] = false;
     hipLaunchKernelGGL(k_init_rows, dim3(cdiv(M, 256)), dim3(256), 0, s, c.slot[0], c.word[0], h->d.bos_idx, M);
     LAUNCHCHK();
     return 0;
@@ -1022,6 +1053,7 @@ extern "C" int vsr_step(vsr_handle* h, int32_t t, int32_t rows_per_image, const 
     const float* in[4] = {h1, c1, h2, c2};
     float* out[4] = {h1_out, c1_out, h2_out, c2_out};
     for (int j = 0; j < 4; ++j) HIPCHK(hipMemcpyAsync(c.st[0][j], in[j], n, hipMemcpyDeviceToDevice, s));
+    c.st16_ok[0] = false;                     // the caller's state has no bf16 image
     hipLaunchKernelGGL(k_step_slots, dim3(cdiv(M, 256)), dim3(256), 0, s, t, slot, prev_gates, c.L, M, c.slot[0], slot_out);
     if (t == 0) hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, c.word[0], h->d.bos_idx, M);
     else hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, prev_words, 1LL, c.word[0], M, V, c.nvalid_dev + 2);
