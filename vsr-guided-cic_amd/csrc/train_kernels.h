@@ -12,9 +12,10 @@
 namespace vsr {
 
 // Transposes, 64 x 64 tiles through LDS, 16 bytes per lane on both sides (256-byte row pieces; the 32 x 32 / 4-byte version
-// moved 1.5 TB/s).  GATHER: row r of the input is row list[r]; BF16: the bf16 image (round-to-nearest-even) goes to out16
-// - the bf16 mode's W operands (gemm_bf16.h) - and the fp32 image is written too (a launch that cannot take the bf16 kernel,
-// e.g. an odd alignment, runs on the fp32 one).  Unaligned shapes (ld or a base not a multiple of 4 floats) take scalar accesses.
+// moved 1.5 TB/s).  GATHER: row r of the input is row list[r]; BF16: ONLY the bf16 image (round-to-nearest-even) is written, to
+// out16 - the bf16 mode's W operands (gemm_bf16.h); the fp32 buffer `out` then only lends its address (the twin is looked up by
+// it) and a launch that names it but cannot take the bf16 kernel is refused (GemmBuilder::launch).  Unaligned shapes (ld or a
+// base not a multiple of 4 floats) take scalar accesses.
 __device__ __forceinline__ uint16_t to_bf16_bits(float x) {
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -54,18 +55,19 @@ __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ i
             for (int e = 0; e < 4; ++e) v[e] = t[4 * q + e][p + 16 * i];
             float* dst = out + (long long)c * ld_out + r;
             if (vout && r + 3 < R) {
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 if (BF16) {
                     uint2 o;
                     o.x = (uint32_t)to_bf16_bits(v[0]) | ((uint32_t)to_bf16_bits(v[1]) << 16);
                     o.y = (uint32_t)to_bf16_bits(v[2]) | ((uint32_t)to_bf16_bits(v[3]) << 16);
                     *reinterpret_cast<uint2*>(out16 + (long long)c * ld_out + r) = o;
+                } else {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             } else {
                 for (int e = 0; e < 4; ++e)
                     if (r + e < R) {
-                        dst[e] = v[e];
                         if (BF16) out16[(long long)c * ld_out + r + e] = to_bf16_bits(v[e]);
+                        else dst[e] = v[e];
                     }
             }
         }

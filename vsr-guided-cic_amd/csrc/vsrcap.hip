@@ -102,6 +102,11 @@ struct vsr_handle {
             if (p >= r.lo && p < r.hi) return r.b + (p - r.lo);
         return nullptr;
     }
+    bool is_train_twin(const float* p) const {       // p lies in a transposed operand of the training pass (bf16 image only)
+        for (size_t i = b16_weights; i < b16.size(); ++i)
+            if (p >= b16[i].lo && p < b16[i].hi) return true;
+        return false;
+    }
     vsr_dims d;
     vsr_weights w;
     bool bound = false, prepared = false;
@@ -235,6 +240,7 @@ struct GemmBuilder {
     int big = 0;       // 2: 128x128 workgroup tiles, 1: 128x64, 0: 64x64 (32x32x2 MFMA); 16: rows-16 kernel (16x16x4 MFMA), r16_tm tiles
     int r16_tm = 0;
     bool a16_all = false;   // bf16 kernel: every segment's A operand has a bf16 image (GemmSeg::A16)
+    bool stale_w = false;   // bf16 mode: a W operand exists only as a bf16 image but the launch does not qualify for the bf16 kernel
     // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
     int finish(const vsr_handle* h) {
         int maxM = 0;
@@ -250,6 +256,13 @@ struct GemmBuilder {
                     ok = w16 && (S.K % 8 == 0) && (S.ldw % 8 == 0) && (S.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(w16) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(S.A) & 15) == 0);
                 }
+            if (!ok) {
+                // the transposing kernels of the training pass write ONLY the bf16 image of such an operand: the fp32 kernel
+                // would read a stale buffer.  (Does not happen for sizes the mode accepts: every K / leading dimension is a
+                // multiple of 8.)
+                for (int i = 0; i < a.nprob; ++i)
+                    for (int sg = 0; sg < a.p[i].nseg; ++sg) stale_w = stale_w || h->is_train_twin(a.p[i].seg[sg].W);
+            }
             if (ok) {
                 a16_all = true;
                 for (int i = 0; i < a.nprob; ++i)
@@ -295,6 +308,7 @@ struct GemmBuilder {
 };
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
+    if (stale_w) return fail("bf16 mode: a GEMM launch names a transposed operand that only exists as a bf16 image but cannot take the bf16 kernel (K / leading dimensions must be multiples of 8)");
     dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : big == 33 ? X3_THREADS : big == 16 ? 512 : 256);
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
