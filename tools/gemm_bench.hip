@@ -22,7 +22,7 @@ using namespace vsr;
 // bf16 twins of the weight buffers (variant 1664 = gemm_nt_bf16w_kernel): same element layout, 2 bytes per element
 struct Twin { const float* f; size_t n; uint16_t* b; };
 static std::vector<Twin> g_twins;
-static bool g_bf16 = false;
+static bool g_bf16 = false, g_a16 = false;     // g_a16: variant 1665 = the bf16 kernel reading bf16 images of A (GemmSeg::A16)
 
 static float* dev_rand(size_t n, unsigned seed) {
     std::vector<float> h(n);
@@ -55,6 +55,7 @@ struct Builder {
     GemmProb& prob(int M, int N, float* C, int ldc) { GemmProb& p = a.p[a.nprob++]; p.M = M; p.N = N; p.C = C; p.ldc = ldc; return p; }
     static void seg(GemmProb& p, const float* A, int lda, const int* idx, const float* W, int ldw, int K) {
         GemmSeg& s = p.seg[p.nseg++]; s.A = A; s.lda = lda; s.a_idx = idx; s.W = g_bf16 ? twin_of(W) : W; s.ldw = ldw; s.K = K;
+        s.A16 = g_a16 ? reinterpret_cast<const uint16_t*>(twin_of(A)) : nullptr;
     }
     int finish() {
         int bm = tm >= 12 ? 128 : 64 * tm, bn = tm >= 12 ? 128 : 64 * tn;
@@ -67,10 +68,11 @@ struct Builder {
         if (tm == 2224) { bm = 128; bn = 256; }
         if (tm == 3300) { bm = 128; bn = 256; }                                      // f32x3 kernel
         if (tm > 1600 && tm <= 1608) { bm = 16 * (tm - 1600); bn = 64 * tn; }      // rows-16 kernel: tm = 1600 + TM, tn = TN
-        if (tm == 1664) { bm = 128; bn = 256; }                                      // bf16 throughput kernel (bf16 W twins)
+        if (tm == 1664 || tm == 1665) { bm = 128; bn = 256; }                        // bf16 throughput kernel (bf16 W twins; 1665: bf16 A images too)
         int ns = 0;
-        if ((tm == 1664 || tm == 3300) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, tm == 1664 ? B16_BK : GEMM_BK);
-        if (!ns) ns = gemm_plan(a, slots, min_iters, bm, bn, tm == 1664 ? B16_BK : GEMM_BK);
+        const bool b16 = tm == 1664 || tm == 1665;
+        if ((b16 || tm == 3300) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, b16 ? B16_BK : GEMM_BK);
+        if (!ns) ns = gemm_plan(a, slots, min_iters, bm, bn, b16 ? B16_BK : GEMM_BK);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
         return ns;
     }
@@ -81,6 +83,7 @@ struct Builder {
                  else if (tm == 1600 + TM_ && tn == 4) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 4>), g, dim3(512), 0, st, a);
         if (tm == 3300) hipLaunchKernelGGL(gemm_nt_f32x3_kernel, g, dim3(X3_THREADS), 0, st, a);
         else if (tm == 1664) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<false>, g, dim3(B16_THREADS), 0, st, a);
+        else if (tm == 1665) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<true>, g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
         R16(1) R16(2) R16(3) R16(4) R16(5) R16(6) R16(7) R16(8)
         else if (tm == 322) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2>), g, b, 0, st, a);
@@ -243,8 +246,9 @@ __global__ __launch_bounds__(512) void feed_kernel(const float* __restrict__ A, 
 // ---- fuzz: random ragged grouped launches (1-3 problems, 1-3 k segments each, row gathers, K tails, odd leading dimensions of C,
 // both work decompositions) of the variant under test against an fp64 host reference.  `tools/gemm_bench fuzz <tm> <tn> [cases] [seed]`
 static int fuzz(int tm, int tn, int cases, unsigned seed) {
-    g_bf16 = tm == 1664;
-    const bool wide = tm == 1664 || tm == 3300;           // the 128 x 256 kernels: K multiples of 8 (bf16 chunks)
+    g_bf16 = tm == 1664 || tm == 1665;
+    g_a16 = tm == 1665;
+    const bool wide = g_bf16 || tm == 3300;           // the 128 x 256 kernels: K multiples of 8 (bf16 chunks)
     unsigned st = seed * 747796405u + 2891336453u;
     auto rnd = [&](int lo, int hi) { st = st * 1664525u + 1013904223u; return lo + (int)((st >> 8) % (unsigned)(hi - lo + 1)); };
     int bad = 0;
@@ -272,7 +276,7 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
                 const int q = wide ? 8 : 4;
                 const int K = q * rnd(1, rnd(0, 3) ? 520 / q : 1600 / q);
                 const int rowsA = rnd(0, 1) ? h.M : h.M + rnd(1, 50);
-                const int lda = K + 4 * rnd(0, 3), woff = q * rnd(0, 4), ldw = woff + K + q * rnd(0, 5);
+                const int lda = g_a16 ? K + 8 * rnd(0, 2) : K + 4 * rnd(0, 3), woff = q * rnd(0, 4), ldw = woff + K + q * rnd(0, 5);
                 float* A = dev_rand((size_t)rowsA * lda, seed * 131 + cs * 17 + p * 5 + sg); to_free.push_back(A);
                 float* W = dev_rand((size_t)h.N * ldw + 64, seed * 137 + cs * 19 + p * 7 + sg); to_free.push_back(W);
                 std::vector<int> idx;
@@ -393,7 +397,8 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 500;
     const int slots = argc > 2 ? atoi(argv[2]) : 1024, min_iters = argc > 3 ? atoi(argv[3]) : 8;
     const int tm = argc > 4 ? atoi(argv[4]) : 1, tn = argc > 5 ? atoi(argv[5]) : 1;
-    g_bf16 = tm == 1664;
+    g_bf16 = tm == 1664 || tm == 1665;
+    g_a16 = tm == 1665;
     // GEMM_ALIGNED=1: hidden sizes rounded to 1024 so that every row stride is a multiple of 128 B (cache-line aligned rows)
     const bool aligned = getenv("GEMM_ALIGNED") != nullptr;
     const int H = aligned ? 1024 : 1000, E = H, D = 2048, A = 512, V = 10000, in1 = H + D + E, in2 = H + D;
@@ -440,7 +445,8 @@ int main(int argc, char** argv) {
         std::vector<double> ref((size_t)m * n);
         for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < kk; ++k) s += (double)hA[(size_t)i * kk + k] * hW[(size_t)j * kk + k]; ref[(size_t)i * n + j] = s; }
         for (int variant = 0; variant < 2; ++variant) {
-            g_bf16 = variant && tm == 1664;
+            g_bf16 = variant && (tm == 1664 || tm == 1665);
+            g_a16 = variant && tm == 1665;
             Builder b(slots, min_iters, variant ? tm : 1, variant ? tn : 1);
             GemmProb& p = b.prob(m, n, Cx, n); Builder::seg(p, A1, kk, nullptr, W, kk, kk);
             int ns = b.finish(); b.launch(0); CK(hipDeviceSynchronize());
@@ -451,7 +457,8 @@ int main(int argc, char** argv) {
         }
     }
 
-    g_bf16 = tm == 1664;
+    g_bf16 = tm == 1664 || tm == 1665;
+    g_a16 = tm == 1665;
     // ---- timing on the decoder shapes
     float* h2 = dev_rand((size_t)M * H, 5); float* h1 = dev_rand((size_t)M * H, 6); float* att = dev_rand((size_t)M * D, 7);
     float* emb = dev_rand((size_t)V * E, 8);
