@@ -2,11 +2,11 @@
 """bench.py - headline benchmark of the VSR captioning decoder hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload beam5|beam5idx|greedy|xe|scst]
-                    [--scaling weak|strong] [--dtype f32|bf16] [--no-cpu] [--no-secondary]
+                    [--scaling weak|strong] [--dtype f32x3|f32|bf16] [--no-cpu] [--no-secondary] [--no-alt]
 
 Headline (BASELINE.json metric, configs[2]): beam-5 decode through ControllableCaptioningModel.beam_search, batch 100
-images per GPU, 36 regions x 2048-d, 10 slots, seq_len 20, vocab 10 000, fp32 (the reference's precision; token parity
-holds in this mode).  A "step" = ONE full decode call on one batch of synthetic inputs already resident in HBM: hoisted
+images per GPU, 36 regions x 2048-d, 10 slots, seq_len 20, vocab 10 000, fp32 operands and accumulation (the reference's
+precision; token parity holds: every GPU test runs in this flavour and in the exact-chain one).  A "step" = ONE full decode call on one batch of synthetic inputs already resident in HBM: hoisted
 statics (vsr_prepare) + 20 timesteps + back-tracking.  tokens/s = B_total * T * steps / wall time (top-1 hypothesis
 tokens).  The default line also carries the second half of the BASELINE metric as "secondary": the XE
 training step (configs[3] shapes; forward + NLL losses + hand-written BPTT + Adam [+ RCCL gradient all-reduce]).
@@ -92,11 +92,12 @@ def cpu_info():
 
 
 # ---------------------------------------------------------------------------------------------- CPU baseline legs
-def cpu_baseline(weights, sample_B, beam, torch, synth):
-    """the CPU oracle (PyTorch CPU, fp32) on a bounded sample of the same synthetic workload, in
-    the reference's AS-WRITTEN op order (per-step recompute of the pooled descriptor / region projection, statics
-    re-gather per beam step, full sort) - the number of record - and HOISTED beside it.  torch.set_num_threads(physical
-    cores); 1 warm-up call, median of 3 timed calls each."""
+def cpu_baseline(weights, sample_B, beam, torch, synth, full_B=0):
+    """the CPU oracle (PyTorch CPU, fp32) on the same synthetic workload, in the reference's AS-WRITTEN
+    op order (per-step recompute of the pooled descriptor / region projection, statics re-gather per beam step, full sort)
+    and HOISTED beside it.  torch.set_num_threads(physical cores).  Bounded sample: sample_B images, 1 warm-up call, median
+    of 3 timed calls each.  full_B > 0: additionally ONE as-written call at the workload's own batch size (M = 500 rows gives
+    the CPU's GEMMs better shapes than the sample's M = 60) - that call is then the `value` of record."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vsr_oracle as vo
     c = CFG
@@ -116,11 +117,26 @@ def cpu_baseline(weights, sample_B, beam, torch, synth):
                 run(det, ctrl)
                 ts.append(time.time() - t0)
         out[flavour] = (sample_B * c["T"] / sorted(ts)[1], sorted(ts)[1])
-    return dict(value=out["as_written"][0], unit="tokens/s", cores=torch.get_num_threads(), kind="port",
-                cpu_model=model, torch=torch.__version__, hoisted_value=out["hoisted"][0],
-                sample="oracle/vsr_oracle.py, %s, %d images x %d steps, fp32; as-written (the reference's op order) median of 3 = "
-                       "%.1f s per call, hoisted variant %.1f s; 1 warm-up call each" %
-                       ("beam-%d" % beam if beam > 1 else "greedy", sample_B, c["T"], out["as_written"][1], out["hoisted"][1]))
+    name = "beam-%d" % beam if beam > 1 else "greedy"
+    res = dict(value=out["as_written"][0], unit="tokens/s", cores=torch.get_num_threads(), kind="port",
+               cpu_model=model, torch=torch.__version__, hoisted_value=out["hoisted"][0], sample_B=sample_B,
+               sample="oracle/vsr_oracle.py, %s, %d images x %d steps, fp32; as-written (the reference's op order) median of 3 = "
+                      "%.1f s per call, hoisted variant %.1f s; 1 warm-up call each" %
+                      (name, sample_B, c["T"], out["as_written"][1], out["hoisted"][1]))
+    if full_B > sample_B:
+        det = torch.from_numpy(synth.make_detections(full_B, c["R0"], c["D"], seed=1000))        # the GPU leg's first batch
+        ctrl = torch.from_numpy(synth.make_ctrl(full_B, c["L"], c["R"], c["D"], seed=1000))
+        o = vo.Oracle(weights, c["T"], 2, as_written=True)
+        with torch.no_grad():
+            t0 = time.time()
+            (o.beam_search(det, ctrl, [EOS, -1], beam, 1) if beam > 1 else o.test(det, ctrl))
+            dt = time.time() - t0
+        res.update(value=full_B * c["T"] / dt, sample_B=full_B, sample12_value=out["as_written"][0],
+                   sample="oracle/vsr_oracle.py, %s, as-written (the reference's op order), fp32: ONE call on the GPU leg's own first "
+                          "batch of %d images x %d steps = %.1f s (value); bounded sample of %d images, median of 3 after a warm-up: "
+                          "%.1f s per call as written (sample12_value), %.1f s hoisted (hoisted_value)" %
+                          (name, full_B, c["T"], dt, sample_B, out["as_written"][1], out["hoisted"][1]))
+    return res
 
 
 def cpu_baseline_xe(weights, sample_B, torch, synth):
@@ -223,8 +239,7 @@ def make_model(torch, synth, dev, train, dtype):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     m = m.to(dev)
     m = m.train() if train else m.eval()
-    if dtype != "f32":
-        m.set_compute_dtype(dtype)
+    m.set_compute_dtype(dtype)
     return m, weights
 
 
@@ -240,11 +255,14 @@ def roofline_block(dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic=No
                 "mfma_tflops_for_reference": achieved, "mfma_frac_of_dense_bf16_peak": achieved / PEAK_BF16_MFMA_TFLOPS}
     peak = PEAK_F32_MFMA_TFLOPS
     if dtype == "f32x3":
-        r = {"bound": "mfma", "kernel": "gemm_nt_f32x3_kernel (fp32 operands split into 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per product)",
+        r = {"bound": "mfma", "kernel": "gemm_nt_f32x3_kernel (fp32 operands split into 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per product; "
+                                         "launches of <= 192 rows: the exact fp32 kernels of gemm_f32.h)",
              "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS / 6.0, "unit": "TFLOP/s (fp32-equivalent)", "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0),
-             "traffic": None, "launches": gemm_seen, "launches_timed": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
+             "traffic": traffic, "launches": gemm_seen, "launches_timed": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
              "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt, "algorithmic_flops_per_launch": gemm_flops / max(gemm_n, 1),
              "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+        if traffic_source:
+            r["traffic_source"] = traffic_source + " (quoted from the committed rocprofv3 PMC passes of this command, not re-measured in this run)"
         return r
     r = {"bound": "mfma",
          "kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32; problems of <= 80 rows: gemm_nt_f32_r16_kernel, v_mfma_f32_16x16x4_f32)",
@@ -311,8 +329,8 @@ def decode_bench(args, D, torch, dist, synth):
     images = c["B"] if strong else world * c["B"]
     name = "beam-5" if beam > 1 else "greedy"
     traffic, tsrc = (None, None)
-    if beam > 1 and not indexed and args.dtype in ("f32", "bf16"):      # the workloads the committed PMC passes were taken on
-        traffic, tsrc = traffic_from_profiles("gemm" if args.dtype == "f32" else "gemm_bf16")
+    if beam > 1 and not indexed:                                        # the workloads the committed PMC passes were taken on
+        traffic, tsrc = traffic_from_profiles({"f32": "gemm", "bf16": "gemm_bf16", "f32x3": "gemm_f32x3"}[args.dtype])
     line = {
         "metric": ("decoded tokens/sec at batch=100, beam=5, 36x2048 regions" + (", index-list region format" if indexed else ""))
                   if beam > 1 else "decoded tokens/sec, greedy, batch=100, 36x2048 regions",
@@ -434,12 +452,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="beam5", choices=["beam5", "beam5idx", "greedy", "xe", "scst"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f32x3", "bf16"],
-                    help="f32 = parity mode (headline); bf16 = throughput mode (bf16 operands, fp32 accumulate, fp32 master weights)")
+    ap.add_argument("--dtype", default="f32x3", choices=["f32", "f32x3", "bf16"],
+                    help="f32x3 = parity mode (headline): fp32 operands, fp32 accumulation, products of launches > 192 rows from three bf16 "
+                         "terms per operand; f32 = the exact fp32 fma chain for every launch; bf16 = throughput mode (bf16 operands, "
+                         "fp32 accumulate, fp32 master weights)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the XE-step leg of the default line")
     ap.add_argument("--no-alt", action="store_true", help="skip the f32x3 / bf16 legs of the default line")
     ap.add_argument("--cpu-sample", type=int, default=12)
+    ap.add_argument("--cpu-full", type=int, default=1, help="1: the CPU baseline's value is ONE as-written call at the workload's own batch size (0: the bounded sample only)")
     ap.add_argument("--batch", type=int, default=0, help="images per batch instead of 100 (experiments only: not the BASELINE workload)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (the measurement); gloo = self-test of the multi-rank path on fewer GPUs than ranks")
@@ -470,19 +491,28 @@ def main():
             xe_line, _ = train_bench(xa, D, torch, dist, synth, max(5, args.steps // 2), 2)
             line["secondary"] = {k: xe_line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                                          "scaling", "dtype", "config", "roofline")}
-        if args.workload == "beam5" and args.dtype == "f32" and not args.no_alt:
-            # the same workload in the two optional GEMM flavours, for the record (never the headline `value`):
-            #   f32x3 = fp32-accurate products on the bf16 matrix cores (same fixtures, same bounds: tests/test_gpu_f32x3.py)
+            if not args.no_alt:
+                # configs[3] names bf16: the same XE step in the throughput mode, and in the exact-chain flavour, side by side
+                line["secondary"]["alt_modes"] = {}
+                for dt in [d for d in ("f32", "bf16") if d != args.dtype]:
+                    xb = argparse.Namespace(**vars(xa))
+                    xb.dtype = dt
+                    bl, _ = train_bench(xb, D, torch, dist, synth, max(5, args.steps // 2), 2)
+                    line["secondary"]["alt_modes"][dt] = {k: bl[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline")}
+        if args.workload == "beam5" and not args.no_alt:
+            # the same workload in the other GEMM flavours, always printed side by side (never the headline `value`):
+            #   f32   = the exact k-ordered fp32 fma chain for every launch (v_mfma_f32_32x32x2_f32)
+            #   f32x3 = fp32 products from three bf16 terms per operand (same fixtures, same bounds: the GPU suite runs in both)
             #   bf16  = throughput mode (tests/test_gpu_bf16.py states its deviation)
             line["alt_modes"] = {}
-            for dt in ("f32x3", "bf16"):
+            for dt in [d for d in ("f32", "f32x3", "bf16") if d != args.dtype]:
                 aa = argparse.Namespace(**vars(args))
                 aa.dtype = dt
                 aa.steps, aa.warmup = max(5, args.steps // 2), 2
                 al, _, _ = decode_bench(aa, D, torch, dist, synth)
                 line["alt_modes"][dt] = {k: al[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline")}
         if D.rank == 0 and D.world == 1 and not args.no_cpu and args.workload != "beam5idx":
-            line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam, torch, synth)
+            line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam, torch, synth, full_B=CFG["B"] if args.cpu_full else 0)
     if D.rank == 0:
         print(json.dumps(line), flush=True)
     if D.world > 1:

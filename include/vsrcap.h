@@ -110,11 +110,11 @@ int vsr_build_decode_cache(vsr_handle* h, float* buffer, size_t n_floats, void* 
 size_t vsr_bf16_weight_bytes(const vsr_handle* h);
 int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream);
 
-/* fp32 GEMM flavour of a handle.  0 (default): exact k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32 - the mode the parity
- * fixtures were generated against.  1 ("f32x3"): every fp32 operand is split into three bf16 terms on its way into LDS
- * (x = hi + mid + lo exactly) and a product is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped cross terms are
- * below one fp32 rounding of the product.  Operands stay fp32 in memory (no copies).  Not bit-identical to mode 0; admitted by
- * the same parity suite (tests/test_gpu_f32x3.py). */
+/* fp32 GEMM flavour of a handle.  1 ("f32x3", the default since round 3): in launches of more than 192 rows every fp32 operand
+ * is split into three bf16 terms on its way into LDS (x = hi + mid + lo exactly) and a product is six v_mfma_f32_32x32x16_bf16
+ * with fp32 accumulation; the dropped cross terms are below one fp32 rounding of the product.  Operands stay fp32 in memory
+ * (no copies); shorter launches use the exact chain.  0: exact k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32 for every
+ * launch.  The two are not bit-identical (a different summation order); every parity test runs in both (tests/conftest.py). */
 int vsr_set_gemm_mode(vsr_handle* h, int32_t mode);
 
 /* ---- workspace ------------------------------------------------------------------------------------ */

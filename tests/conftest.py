@@ -17,6 +17,42 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- both fp32 GEMM flavours in ONE pytest invocation -------------------------------------------------------------------
+# Every `-m gpu` test of the decoder modules below runs twice: with the default flavour ('f32x3': launches of more than 192
+# rows form their products from three bf16 terms per fp32 operand, csrc/gemm_f32x3.h) and with 'f32' (the exact fma chain for
+# every launch).  Same fixtures, same bounds: that is what admits f32x3 as the parity-mode default.  The flavour is applied
+# through models.set_default_compute_dtype(), i.e. the compute dtype a freshly constructed model starts in; tests that pick
+# a dtype themselves (test_gpu_bf16.py, test_gpu_f32x3.py) are not doubled.  Child processes (the data-parallel workers,
+# bench.py) receive it as VSR_COMPUTE_DTYPE.
+FLAVOURS = ("f32x3", "f32")
+DUAL_FLAVOUR_MODULES = ("test_gpu_parity", "test_gpu_configs", "test_gpu_train", "test_gpu_regions", "test_aa_gpu_dp",
+                        "test_gpu_headline", "test_gpu_graph", "test_gpu_skinny", "test_gpu_train_indexed")
+
+
+def pytest_generate_tests(metafunc):
+    mod = metafunc.module.__name__.rsplit(".", 1)[-1]
+    if "gemm_flavour" in metafunc.fixturenames and mod in DUAL_FLAVOUR_MODULES and metafunc.definition.get_closest_marker("gpu"):
+        metafunc.parametrize("gemm_flavour", FLAVOURS, indirect=True, scope="session")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def gemm_flavour(request):
+    flavour = getattr(request, "param", None)
+    if flavour is None:
+        yield None
+        return
+    import models
+    old = models.set_default_compute_dtype(flavour)
+    old_env = os.environ.get("VSR_COMPUTE_DTYPE")
+    os.environ["VSR_COMPUTE_DTYPE"] = flavour
+    yield flavour
+    models.set_default_compute_dtype(old)
+    if old_env is None:
+        os.environ.pop("VSR_COMPUTE_DTYPE", None)
+    else:
+        os.environ["VSR_COMPUTE_DTYPE"] = old_env
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(str(z["meta"]))

@@ -292,25 +292,6 @@ def test_constant_logit_rows_fall_back_to_full_row_selection():
     np.testing.assert_allclose(lw[:, 0].cpu().numpy(), -np.log(cfg["V"]), atol=1e-5)
 
 
-def test_eos_on_both_streams_freezes_hypotheses():
-    """eos on BOTH streams exercises the freeze branch of beam_search (CaptioningModel.py:143-150)."""
-    import vsr_oracle as vo
-    meta, _ = load_golden("g3_beam_small")
-    cfg = meta["cfg"]
-    m, w = _model_for(meta)
-    o = vo.Oracle(w, cfg["T"], 2, as_written=False)
-    det, ctrl = helpers.decode_inputs(cfg, meta["seed"])
-    with torch.no_grad():
-        gw, gg = o.test(det, ctrl)
-    eos = [int(gw[0, 2]), int(gg[0, 2])]
-    with torch.no_grad():
-        (ow, og), olp, osc = o.beam_search(det, ctrl, eos, 3, 1, return_scores=True)
-        eng = m._engine(torch.device(DEV))
-        B = eng.prepare(det.to(DEV), ctrl.to(DEV), 3, m._weights_version())
-        (w_, g_), (lw, lg), sc = eng.beam(B, torch.device(DEV), 3, 1, eos[0], eos[1])
-    np.testing.assert_allclose(sc[:, 0].cpu().numpy(), osc[:, 0].numpy(), atol=1e-4, rtol=0)
-
-
 def test_eval_side_batching_equals_per_image_calls():
     """one beam_search_v call for all images of an eval batch == the reference's per-image calls."""
     from vsrcap import synth

@@ -49,6 +49,9 @@ __global__ void k_f32_to_bf16(const float* __restrict__ src, uint16_t* __restric
     }
 }
 
+#ifndef B16_ABLATE
+#define B16_ABLATE 0     // diagnostics only (tools/gemm_bench.hip): bit 0 = no global loads in the loop, bit 1 = no LDS refill, bit 2 = no epilogue stores
+#endif
 constexpr int B16_BK = 64;                                // k-tile: 64 bf16 = one 128-byte line per W row, two lines per fp32 A row
 
 // Asynchronous 16-byte global loads.  The k loop keeps TWO tiles in flight per thread (two register sets).  Written with plain
@@ -163,7 +166,7 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
             for (int i = 0; i < 32 / RPP; ++i) {
                 const int sr = tid / TPR + RPP * i;
                 const int m = m0 + band * 32 + sr;
-                if (m < P.M && n < P.N) {
+                if (m < P.M && n < P.N && !((B16_ABLATE & 4) && m + n > 0)) {
                     const float4 v = *reinterpret_cast<const float4*>(stage + sr * ST_LD + c4);
                     float* dst = C + (long long)m * P.ldc + n;
                     if (vec_ok && n + 3 < P.N) {
@@ -340,8 +343,8 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
         auto step = [&](auto S) __attribute__((always_inline)) {
             if (it + 1 < it1) {
                 landed_set(S, it + 2 < it1);
-                store_tile(S, cur ^ 1);
-                if (it + 3 < it1) issue(S);
+                if (!(B16_ABLATE & 2)) store_tile(S, cur ^ 1);
+                if (it + 3 < it1 && !(B16_ABLATE & 1)) issue(S);
             }
             end_of_ktile(std::false_type{});
         };
@@ -366,7 +369,7 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
             const uint16_t* a_base = sA(cur) + (wm * (32 * TM) + r) * B16_ROW + 8 * hh;
             const uint16_t* b_base = sB(cur) + (wn * (32 * TN) + r) * B16_ROW + 8 * hh;
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
+            for (int kk = 0; kk < ((B16_ABLATE & 8) ? 0 : BK / 16); ++kk) {
                 bf16x8_t av[TM], bv[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const bf16x8_t*>(a_base + i * 32 * B16_ROW + kk * 16);

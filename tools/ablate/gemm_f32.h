@@ -65,13 +65,24 @@ struct GemmArgs {
     int G;               // workgroups with a non-empty range (1 <= G <= total_iters); grid = 8 * ceil(G / 8)
     int nslab;           // slabs per tile (S)
     int aligned;         // 0: stream-K ranges (gemm_plan); 1: one k-aligned piece of one tile per workgroup (gemm_plan_aligned)
+    unsigned long long* dbg;   // diagnostics build only (GEMM_STAMP): per-workgroup {shader cycles, 100 MHz ticks}
 };
 
-// tile index -> tile origin: m fastest (the m-tiles of a weight n-tile are neighbours)
+// tile index -> tile origin.  GEMM_TILE_ORDER 0: m fastest (the m-tiles of a weight n-tile are neighbours), 1: n fastest
+#ifndef GEMM_TILE_ORDER
+#define GEMM_TILE_ORDER 0
+#endif
 __device__ __forceinline__ void gemm_tile_origin(const GemmProb& P, int tile, int BM, int BN, int& m0, int& n0) {
+#if GEMM_TILE_ORDER == 1
+    m0 = (tile / P.tiles_n) * BM; n0 = (tile % P.tiles_n) * BN;
+#else
     m0 = (tile % P.tiles_m) * BM; n0 = (tile / P.tiles_m) * BN;
+#endif
 }
 
+#ifndef GEMM_ABLATE
+#define GEMM_ABLATE 0    // diagnostics only (tools/gemm_bench.hip): 1 = no global loads in the loop, 2 = also no LDS refill
+#endif
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LDS = GEMM_BK + 4;
 
@@ -187,7 +198,11 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
             open_segment(l_seg + 1, 0);
         }
         const bool kin = l_k + lc4 < l_K;                  // K tail: read a valid address, store zeros
+#if defined(GEMM_L1HOT)
+        const int ko = 0;                                  // diagnostics: every k-tile re-reads the same (L1-resident) lines
+#else
         const int ko = kin ? l_k : 0;
+#endif
 #pragma unroll
         for (int i = 0; i < LA; ++i) ra[i] = *reinterpret_cast<const float4*>(pa[i] + ko);
 #pragma unroll
@@ -292,6 +307,9 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
         }
     };
 
+#if defined(GEMM_STAMP)
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     {
         const int kt = decode(it0);
         open_tile(c_prob, c_tile, kt);
@@ -300,6 +318,9 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
     store_tile(0);
     __syncthreads();
     int cur = 0;
+#if defined(GEMM_PHASES)
+    unsigned long long phs[5] = {0, 0, 0, 0, 0};
+#endif
     // Outer loop: one tile piece; inner loop: its k iterations.  The accumulator is only ever touched by MFMAs
     // inside the inner loop, so it stays in the accumulator registers (a VALU read/zero of it inside the k loop
     // made hipcc shuttle all 16 registers through v_accvgpr_read/write and drain the MFMA pipe every iteration).
@@ -314,7 +335,13 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
         const int n_it = c_left;
         for (int j_it = 0; j_it < n_it; ++j_it, ++it) {
             const bool more = it + 1 < it1;
-            if (more) load_next();                         // global -> registers, in flight during the MFMAs
+#if defined(GEMM_PHASES)
+            const unsigned long long ph0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (more && GEMM_ABLATE < 1) load_next();      // global -> registers, in flight during the MFMAs
+#if defined(GEMM_PHASES)
+            const unsigned long long ph1 = __builtin_amdgcn_s_memtime();
+#endif
             const float* a_base = sA(cur) + (wm * (32 * TM) + r) * GEMM_LDS + 4 * hh;
             const float* b_base = sB(cur) + (wn * (32 * TN) + r) * GEMM_LDS + 4 * hh;
 #pragma unroll
@@ -334,15 +361,40 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
                     }
             }
-            if (more) {
+#if defined(GEMM_PHASES)
+            asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15]));
+            const unsigned long long ph2 = __builtin_amdgcn_s_memtime();
+            if (more) store_tile(cur ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long ph3 = __builtin_amdgcn_s_memtime();
+            if (more) { __syncthreads(); cur ^= 1; }
+            const unsigned long long ph4 = __builtin_amdgcn_s_memtime();
+            phs[0] += ph1 - ph0; phs[1] += ph2 - ph1; phs[2] += ph3 - ph2; phs[3] += ph4 - ph3; phs[4] += 1;
+#else
+            if (more && GEMM_ABLATE < 2) {
                 store_tile(cur ^ 1);                       // other buffer: nobody reads it in this iteration
                 __syncthreads();
                 cur ^= 1;
             }
+#endif
         }
-        flush(acc, sA(cur ^ 1));
+        if (GEMM_ABLATE < 3) flush(acc, sA(cur ^ 1));
+        else asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][15]));
         if (it < it1) decode(it);
     }
+#if defined(GEMM_PHASES)
+    if (args.dbg && tid == 0) for (int q = 0; q < 5; ++q) args.dbg[8 * g + q] = phs[q];
+#endif
+#if defined(GEMM_STAMP)
+    if (args.dbg && tid == 0) {
+        args.dbg[4 * g] = __builtin_amdgcn_s_memtime() - st0;
+        args.dbg[4 * g + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
+        args.dbg[4 * g + 2] = sr0;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        args.dbg[4 * g + 3] = xcc;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -594,45 +646,64 @@ void gemm_nt_f32_r16_kernel(const GemmArgs args) {
             // Next tile's global loads, STAGGERED between the two waves of a SIMD (waves w and w + 4 = the two k halves): the
             // k-half-0 wave issues its loads in front of its MFMAs, the k-half-1 wave behind its third MFMA group, so one of
             // them multiplies while the other queues on the CU's address path (lock-stepped, both would queue, then both multiply).
+#ifndef R16_LOADPOS
+#define R16_LOADPOS 0
+#endif
             auto loads = [&]() __attribute__((always_inline)) {
-                if (more) {
+                if (more && GEMM_ABLATE < 1) {
 #pragma unroll
                     for (int i = 0; i < LA; ++i) load_a(i);
 #pragma unroll
                     for (int i = 0; i < LB; ++i) load_b(i);
                 }
             };
-            loads();
+            if (R16_LOADPOS == 0 || (R16_LOADPOS == 1 && wk == 0)) loads();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (R16_LOADPOS == 2 || (R16_LOADPOS == 1 && wk == 1)) loads();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+#ifndef R16_MIDREFILL
+#define R16_MIDREFILL 1
+#endif
+#if R16_MIDREFILL == 1
             // refill of the OTHER k buffer (free since the barrier that ended the previous iteration) in the middle of the MFMA
             // stream: its ds_writes and the wait for the loads overlap the partner wave's MFMAs; only the barrier is left at the end
             __builtin_amdgcn_sched_barrier(0);
-            if (more) store_tile(cur ^ 1);
+            if (more && GEMM_ABLATE < 2) store_tile(cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+#if R16_MIDREFILL == 2
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && GEMM_ABLATE < 2) store_tile(cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (more) {
+            if (more && GEMM_ABLATE < 2) {
+#if R16_MIDREFILL == 0
+                store_tile(cur ^ 1);
+#endif
                 __syncthreads();
                 cur ^= 1;
             }
         }
-        flush(acc, sA(cur ^ 1));
+        if (GEMM_ABLATE < 3) flush(acc, sA(cur ^ 1));
+        else asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[TM - 1][TN - 1][3]));
         if (it < it1) decode(it);
     }
 }

@@ -23,6 +23,9 @@
 
 namespace vsr {
 
+#ifndef X3_EXP
+#define X3_EXP 0      // diagnostics (tools/gemm_bench.hip): 1 no split, 2 no global loads in the loop, 3 one MFMA term of six, 5 no operand reads from LDS
+#endif
 constexpr int X3_BK = 32;
 constexpr int X3_ROW = 32;                               // bf16 elements per LDS row (64 bytes, unpadded, XOR-swizzled chunks)
 
@@ -39,7 +42,7 @@ __device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t&
 // 16 waves per workgroup, like gemm_bf16.h: waves 0-7 MULTIPLY (2 x 4, 64 x 64 per wave, two per SIMD), waves 8-15 MOVE data
 // (asynchronous global loads two k-tiles ahead, the three-way split, ds_write into the buffer the multipliers are not reading);
 // one barrier per k-tile.  With one kind of wave (this file's first version, 8 waves) a k-tile cost
-// [load wait + split + LDS refill] + [18 ds_read + 24 MFMA per k-step] = 3.3 us; the ablations (tools/ablate/) put 175 us of MFMA next to
+// [load wait + split + LDS refill] + [18 ds_read + 24 MFMA per k-step] = 3.3 us; the X3_EXP ablations put 175 us of MFMA next to
 // 195 us of split / load / LDS time per decoder step, and those now overlap.
 constexpr int X3_THREADS = 1024;
 __global__ __launch_bounds__(X3_THREADS)
@@ -238,8 +241,12 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
         auto put = [&](uint16_t* buf, int R, f32x4_t v, bool zero) __attribute__((always_inline)) {
             if (zero) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
             uint32_t h0, m0, l0, h1, m1, l1;
+#if X3_EXP == 1
+            h0 = __float_as_uint(v.x); m0 = __float_as_uint(v.y); l0 = 0; h1 = __float_as_uint(v.z); m1 = __float_as_uint(v.w); l1 = 0;
+#else
             split3(v.x, v.y, h0, m0, l0);
             split3(v.z, v.w, h1, m1, l1);
+#endif
             const int pos = R * X3_ROW + 8 * ((lk >> 3) ^ ((R >> 2) & 3)) + (lk & 4);
             *reinterpret_cast<uint2*>(buf + pos) = make_uint2(h0, h1);
             *reinterpret_cast<uint2*>(buf + PLANE + pos) = make_uint2(m0, m1);
@@ -268,7 +275,7 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
             if (it + 1 < it1) {
                 landed_set(S, it + 2 < it1);
                 store_tile(S, cur ^ 1);
-                if (it + 3 < it1) issue(S);
+                if (it + 3 < it1 && X3_EXP != 2) issue(S);
             }
             end_of_ktile(std::false_type{});
         };
@@ -298,6 +305,9 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
             for (int kk = 0; kk < BK / 16; ++kk) {
                 const int ch = 8 * ((2 * kk + hh) ^ swz);  // lane (r, hh) reads k = 8 hh + 16 kk .. +7: chunk 2 kk + hh, swizzled
                 bf16x8_t ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#if X3_EXP == 5
+                if (it > it0 + 1000000) {                  // diagnostics: operands never re-read from LDS
+#endif
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[i] = *reinterpret_cast<const bf16x8_t*>(a_row + i * 32 * X3_ROW + ch);
@@ -310,16 +320,24 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
                     bm[j] = *reinterpret_cast<const bf16x8_t*>(b_row + PLANE + j * 32 * X3_ROW + ch);
                     bl[j] = *reinterpret_cast<const bf16x8_t*>(b_row + 2 * PLANE + j * 32 * X3_ROW + ch);
                 }
+#if X3_EXP == 5
+                } else {
+                    for (int i = 0; i < TM; ++i) { asm volatile("" : "=v"(ah[i])); asm volatile("" : "=v"(am[i])); asm volatile("" : "=v"(al[i])); }
+                    for (int j = 0; j < TN; ++j) { asm volatile("" : "=v"(bh[j])); asm volatile("" : "=v"(bm[j])); asm volatile("" : "=v"(bl[j])); }
+                }
+#endif
                 // smallest terms first, the leading product last
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                        if (X3_EXP != 3) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             }

@@ -9,11 +9,26 @@
 #include <cstring>
 #include <vector>
 
+// -DGEMM_BENCH_ABLATE: the diagnostic COPIES of the three GEMM headers under tools/ablate/ (round-2 state, with the -D hooks
+// GEMM_ABLATE / GEMM_STAMP / GEMM_PHASES / GEMM_L1HOT / X3_EXP / B16_ABLATE / R16_* the measurements in DESIGN.md section 4 were
+// taken with).  The product headers under csrc/ have one code path each and no such hooks.
+#if defined(GEMM_BENCH_ABLATE)
+#include "ablate/gemm_f32.h"
+#include "gemm_bf16x3.h"
+#include "gemm_dma_variant.h"
+#include "ablate/gemm_f32x3.h"
+#include "ablate/gemm_bf16.h"
+#else
+#if defined(GEMM_STAMP) || defined(GEMM_PHASES) || defined(GEMM_ABLATE) || defined(X3_EXP) || defined(B16_ABLATE)
+#error "ablation / stamp hooks live in tools/ablate/: add -DGEMM_BENCH_ABLATE"
+#endif
+#define GEMM_ABLATE 0
 #include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
 #include "gemm_bf16x3.h"
 #include "gemm_dma_variant.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_f32x3.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_bf16.h"
+#endif
 
 using namespace vsr;
 

@@ -11,19 +11,30 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "vsrcap.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "gemm_f32.h"), os.path.join(HERE, "csrc", "gemm_bf16.h"), os.path.join(HERE, "csrc", "gemm_f32x3.h"), os.path.join(HERE, "csrc", "ssp_kernels.h"), os.path.join(HERE, "csrc", "ssp.inc.h"), os.path.join(HERE, "csrc", "kernels.h"),
-        os.path.join(HERE, "csrc", "train_kernels.h"), os.path.join(HERE, "csrc", "train.inc.h"),
-        os.path.join(HERE, "csrc", "cider.inc.h"),
-        os.path.join(os.path.dirname(HERE), "include", "vsrcap.h")]
+GEMM_HEADERS = [os.path.join(HERE, "csrc", f) for f in ("gemm_f32.h", "gemm_bf16.h", "gemm_f32x3.h")]
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".h", ".hip"))) + \
+       [os.path.join(os.path.dirname(HERE), "include", "vsrcap.h")]
 OUT = os.path.join(HERE, "vsrcap", "libvsrcap.so")
 # standalone GEMM check / timing tool (tools/README.md); its `fuzz` mode is run by tests/test_gpu_gemm_fuzz.py
 TOOL_SRC = os.path.join(os.path.dirname(HERE), "tools", "gemm_bench.hip")
-TOOL_DEPS = [TOOL_SRC, os.path.join(os.path.dirname(HERE), "tools", "gemm_bf16x3.h"), os.path.join(os.path.dirname(HERE), "tools", "gemm_dma_variant.h")] + DEPS[1:4]
+TOOL_DEPS = [TOOL_SRC, os.path.join(os.path.dirname(HERE), "tools", "gemm_bf16x3.h"), os.path.join(os.path.dirname(HERE), "tools", "gemm_dma_variant.h")] + GEMM_HEADERS
 TOOL_OUT = os.path.join(os.path.dirname(HERE), "tools", "gemm_bench")
+
+
+STAMP = OUT + ".flags"      # the extra hipcc flags the library on disk was built with
+
+
+def _flags():
+    return os.environ.get("VSR_EXTRA_HIPCC_FLAGS", "").strip()
 
 
 def needs_build():
     if not os.path.exists(OUT):
+        return True
+    # a library built with other extra flags (a diagnostics build) must never be picked up by a later plain run.  A shipped
+    # library without a stamp file (the GPU box receives the .so, the stamp travels with it when present) counts as plain.
+    built_with = open(STAMP).read().strip() if os.path.exists(STAMP) else ""
+    if built_with != _flags():
         return True
     t = os.path.getmtime(OUT)
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
@@ -36,9 +47,11 @@ def build(force=False, verbose=False):
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", OUT + ".tmp", SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    cmd[1:1] = os.environ.get("VSR_EXTRA_HIPCC_FLAGS", "").split()         # diagnostics builds (-DATT_ABLATE=..., -DGEMM_STAMP, ...)
+    cmd[1:1] = _flags().split()              # experiments only (e.g. -save-temps); recorded in the stamp so that a later plain run rebuilds
     subprocess.run(cmd, check=True)
     os.replace(OUT + ".tmp", OUT)
+    with open(STAMP, "w") as f:
+        f.write(_flags())
     return OUT
 
 

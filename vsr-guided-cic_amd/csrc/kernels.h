@@ -343,9 +343,6 @@ struct Gate2Args {
     uint16_t* g_t16 = nullptr;      // optional bf16 image of g_t (bf16 GEMM mode)
 };
 
-#ifndef ATT_ABLATE
-#define ATT_ABLATE 0     // diagnostics builds only: 1 no slab sums, 2 no scores, 3 no weighted sum (results are then wrong)
-#endif
 template <int NT>
 __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* __restrict__ hA, const float* __restrict__ sa,
                                                 const float* __restrict__ sent, const float* __restrict__ P,
@@ -371,10 +368,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     const int k = slot ? slot[row] : fixed_slot;
     const long long sl = (long long)img * L + k;
     const bool fused = g2.c2a != nullptr;
-    if (fused && ATT_ABLATE == 1) {
-        for (int c = tid; c < A; c += NT) { hA_s[c] = 0.01f; sa_s[c] = 0.02f; }
-        for (int c = tid; c < D; c += NT) sent_s[c] = 0.03f;
-    } else if (fused) {
+    if (fused) {
         // Slab sums of the S2 GEMM for this row.  FOUR columns per thread and pass with every slab load (and the g_t operands)
         // issued before the first use: one column per loop iteration made each iteration's loads wait for the previous
         // iteration's global store (8 dependent L2 round trips per row: 10 of the kernel's 34 us).
@@ -456,8 +450,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     // loads are all in flight before the first tanh (one L2 round trip per pass instead of one per row)
     const float* mk_row = rmask + sl * R;
     constexpr int QN = NT == 512 ? 5 : 4;        // rows per wave and pass: 8 waves x 5 cover the 37 score rows of R = 36 at once
-    if (ATT_ABLATE == 2) { for (int j = tid; j < R + 1; j += NT) z_s[j] = 0.1f * j; }
-    for (int r0 = wave; r0 < R + 1 && ATT_ABLATE != 2; r0 += QN * NW) {
+    for (int r0 = wave; r0 < R + 1; r0 += QN * NW) {
         float sc[QN];
 #pragma unroll
         for (int q = 0; q < QN; ++q) sc[q] = 0.f;
@@ -539,7 +532,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     // weighted sum.  Rows with alpha == 0 (zero padding) are skipped: no HBM read for them.  Four region rows are in
     // flight per thread (independent loads) so that the 8 KB rows stream instead of paying one L2/HBM latency each.
     const float a0 = z_s[0];
-    for (int d = tid * 4; d < D && ATT_ABLATE != 3; d += 4 * NT) {
+    for (int d = tid * 4; d < D; d += 4 * NT) {
         const float4 s = *reinterpret_cast<const float4*>(srow + d);
         float4 acc = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
         int r = 0;

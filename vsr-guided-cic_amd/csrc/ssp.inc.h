@@ -17,6 +17,7 @@ extern "C" int vsr_ssp_create(vsr_ssp** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("vsr_ssp_create: no HIP device");
     vsr_ssp* e = new vsr_ssp();
+    e->cfg.x3_on = false;            // the ordering models stay on the exact fp32 chain (their fixtures pin integer-truncated log-probs)
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -116,7 +117,7 @@ extern "C" int vsr_ssp_generate(vsr_ssp* e, const int64_t* verbs, const int32_t*
     const vsr_ssp_weights& w = e->w;
     const int H = SSP_H, L = SSP_LEN;
     HIPCHK(hipMemsetAsync(ws.bad, 0, 4 * sizeof(int), s));
-    hipLaunchKernelGGL(k_ssp_init, dim3(cdiv(S * (L + 1), 256)), dim3(256), 0, s, roles, S, ws.remain, ws.tokens, pred, logp);
+    hipLaunchKernelGGL(k_ssp_init, dim3(cdiv(S * (L + 1), 256)), dim3(256), 0, s, roles, S, ws.remain, ws.tokens, pred, logp, ws.bad);
     // ---- encoder (sort_modules.py:50-62): embeddings -> fc_feat -> 3 pre-LN layers -> LN
     int R = S * L;
     hipLaunchKernelGGL(k_ssp_embed, dim3(R), dim3(128), 0, s, roles, L, L, w.sr_embed, verbs, w.v_embed, w.n_verbs, S, ws.y, ws.bad);

@@ -147,10 +147,19 @@ __global__ __launch_bounds__(64) void k_ssp_select(const float* __restrict__ log
     }
 }
 
+// A role id outside [0, SSP_ROLES) is not "remaining" (k_ssp_select indexes the 26 logits with it) and is counted in `bad`;
+// the reference raises IndexError in its embedding for such an id (sort_model.py:108), the host wrapper does the same.
 __global__ void k_ssp_init(const int* __restrict__ roles, int S, int* __restrict__ remain, int* __restrict__ tokens, int* __restrict__ pred,
-                           float* __restrict__ logp) {
+                           float* __restrict__ logp, int* __restrict__ bad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < S * SSP_LEN) { remain[i] = roles[i] != 0; pred[i] = 0; logp[i] = 0.f; }
+    if (i < S * SSP_LEN) {
+        const int r = roles[i];
+        const bool ok = r >= 0 && r < SSP_ROLES;
+        if (!ok) atomicAdd(bad, 1);
+        remain[i] = ok && r != 0;
+        pred[i] = 0;
+        logp[i] = 0.f;
+    }
     if (i < S * (SSP_LEN + 1)) tokens[i] = 0;
 }
 

@@ -93,7 +93,7 @@ struct vsr_handle {
     TrainCtx* tc = nullptr;
     // bf16 throughput mode (gemm_bf16.h): off unless vsr_refresh_bf16_weights() has been given a buffer
     bool bf16_on = false;
-    bool x3_on = false;               // fp32 products through three bf16 terms per operand (gemm_f32x3.h); fp32 operands, no copies
+    bool x3_on = true;                // launches of >= gemm_x3_min_rows rows: fp32 products through three bf16 terms per operand (gemm_f32x3.h); fp32 operands, no copies.  vsr_set_gemm_mode(h, 0): exact fma chain everywhere
     std::vector<Bf16Range> b16;        // weights (refresh) + the training pass's transposed operands (carve_train)
     size_t b16_weights = 0;            // entries of b16 that belong to the weights
     int gemm_slots_bf16 = 256;         // ONE 16-wave workgroup per CU (108 KB of LDS: two 128+256-row x 64-k bf16 buffers; 147 KB for f32x3)
@@ -540,8 +540,9 @@ extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t byte
     return 0;
 }
 
-// fp32 GEMM flavour: 0 = exact k-ordered fma chain (v_mfma_f32_32x32x2_f32; the default and the mode every fixture was made for),
-// 1 = "f32x3": each fp32 operand split into three bf16 terms, six bf16 MFMAs per product, fp32 accumulation (gemm_f32x3.h)
+// fp32 GEMM flavour: 0 = exact k-ordered fma chain (v_mfma_f32_32x32x2_f32) for every launch,
+// 1 (default since round 3) = "f32x3" for launches of more than 192 rows: each fp32 operand split into three bf16 terms, six bf16
+// MFMAs per product, fp32 accumulation (gemm_f32x3.h).  Every reference fixture is checked in both (tests/conftest.py).
 extern "C" int vsr_set_gemm_mode(vsr_handle* h, int32_t mode) {
     if (!h) return fail("vsr_set_gemm_mode: null handle");
     if (mode != 0 && mode != 1) return fail("vsr_set_gemm_mode: mode %d not in {0, 1}", mode);

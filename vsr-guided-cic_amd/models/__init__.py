@@ -4,8 +4,8 @@ coco_scripts/eval_coco.py:6,10) resolve here, so the reference's scripts stay th
 models are the inference side only (generate / forward as eval_coco.py calls them); their training scripts are out of scope.
 """
 from .CaptioningModel import CaptioningModel as _CaptioningModel
-from .controllable_captioning import ControllableCaptioningModel
+from .controllable_captioning import ControllableCaptioningModel, set_default_compute_dtype
 from .sinkhorn_network import SinkhornNet
 from .sort_model import S_SSP
 
-__all__ = ["ControllableCaptioningModel", "_CaptioningModel", "SinkhornNet", "S_SSP"]
+__all__ = ["ControllableCaptioningModel", "_CaptioningModel", "SinkhornNet", "S_SSP", "set_default_compute_dtype"]

@@ -18,6 +18,21 @@ from .CaptioningModel import CaptioningModel
 from vsrcap.engine import Engine
 
 
+# GEMM flavour a new model starts in.  'f32x3' since round 3: launches of more than 192 rows multiply on the bf16 matrix cores
+# with every fp32 operand split into three bf16 terms (csrc/gemm_f32x3.h); shorter launches stay on the exact fp32 fma chain.
+# The whole GPU suite runs in both flavours (tests/conftest.py parametrises this default), which is what admits it.
+DEFAULT_COMPUTE_DTYPE = 'f32x3'
+
+
+def set_default_compute_dtype(dtype):
+    """compute dtype of models constructed from now on ('f32' = exact fma chain everywhere, 'f32x3', 'bf16'); returns the old one"""
+    global DEFAULT_COMPUTE_DTYPE
+    if dtype not in ('f32', 'bf16', 'f32x3'):
+        raise ValueError("compute dtype must be 'f32', 'f32x3' or 'bf16'")
+    old, DEFAULT_COMPUTE_DTYPE = DEFAULT_COMPUTE_DTYPE, dtype
+    return old
+
+
 class ControllableCaptioningModel(CaptioningModel):
     def __init__(self, seq_len, vocab_size, bos_idx, det_feat_size=2048, input_encoding_size=1000, rnn_size=1000,
                  att_size=512, h2_first_lstm=True, img_second_lstm=False, dataset='coco', *, verb_2_vob_all=None):
@@ -70,12 +85,13 @@ class ControllableCaptioningModel(CaptioningModel):
         # (t.data.copy_, DLPack / custom-kernel writes, p.data edits), or call invalidate_cache() after such a write
         self.force_prepare = False
         # VSR_COMPUTE_DTYPE lets a whole test run (or an unchanged reference script) select the GEMM flavour without code changes
-        self.compute_dtype = os.environ.get('VSR_COMPUTE_DTYPE', 'f32')
+        self.compute_dtype = os.environ.get('VSR_COMPUTE_DTYPE', DEFAULT_COMPUTE_DTYPE)
 
     def set_compute_dtype(self, dtype):
-        """'f32' (default): the reference's precision, the mode token parity and the 1e-4 loss bound hold in.
-        'f32x3': fp32-accurate products on the bf16 matrix cores (each fp32 operand split into three bf16 terms, six MFMAs per
-        product, fp32 accumulation; csrc/gemm_f32x3.h) - same operands, same fixtures, a different summation order.
+        """'f32x3' (default): fp32 operands and fp32 accumulation; launches of more than 192 rows form their products on the
+        bf16 matrix cores (each fp32 operand split into three bf16 terms, six MFMAs per product; csrc/gemm_f32x3.h), the rest
+        on the exact fma chain.  Token parity and the 1e-4 loss bound hold (every GPU test runs in this flavour and in 'f32').
+        'f32': the exact k-ordered fp32 fma chain (v_mfma_f32_32x32x2_f32) for every launch.
         'bf16': throughput mode - matrix products take bf16 operands with fp32 accumulation (v_mfma_f32_32x32x16_bf16);
         parameters, optimizer state, states and reductions stay fp32.  Not a parity mode."""
         if dtype not in ('f32', 'bf16', 'f32x3'):
@@ -108,6 +124,11 @@ class ControllableCaptioningModel(CaptioningModel):
         if device.index is None:
             device = torch.device('cuda', torch.cuda.current_device())
         if self._eng is None or self._eng.device != device:
+            if self._eng is not None and self._eng.grad_sink is not None:
+                # a DataParallelStep holds this engine and its flat gradient buffer: a silent replacement would send the next
+                # backward to autograd's in-place accumulation into views nobody zeroes
+                raise RuntimeError("the model moved from %s to %s while a gradient sink (parallel.DataParallelStep) is attached to "
+                                   "its engine: build the DataParallelStep after the move" % (self._eng.device, device))
             # one handle per device; its launches run under torch.cuda.device(device) whatever the caller's current device is
             self._eng = Engine(dict(seq_len=self.seq_len, vocab_size=self.vocab_size, bos_idx=self.bos_idx,
                                     det_feat_size=self.det_feat_size, input_encoding_size=self.input_encoding_size,

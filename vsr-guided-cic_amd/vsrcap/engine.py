@@ -125,9 +125,10 @@ class Engine:
         _lib.check(self.lib.vsr_set_verb_table(self.h, _ptr(rp), _ptr(fl), n))
 
     def set_gemm_mode(self, x3):
-        """False: exact fp32 fma chain (default); True: "f32x3" (three bf16 terms per fp32 operand, include/vsrcap.h)"""
+        """True (the library's default): "f32x3" for launches of more than 192 rows (three bf16 terms per fp32 operand,
+        include/vsrcap.h); False: the exact fp32 fma chain for every launch"""
         x3 = bool(x3)
-        if x3 != getattr(self, "_x3", False):
+        if x3 != getattr(self, "_x3", True):
             _lib.check(self.lib.vsr_set_gemm_mode(self.h, 1 if x3 else 0))
             self._x3 = x3
             self._cache_key = None

@@ -77,33 +77,6 @@ class FlatGrads:
         return self.flat[lo:hi]
 
 
-def allreduce_gradients(params, bucket_bytes=64 << 20, group=None):
-    """Generic helper (any model, any backend): SUM-all-reduce .grad of params in flat buckets.  DataParallelStep does
-    not use it (its gradients already live in one flat buffer)."""
-    params = [p for p in params if p.grad is not None]
-    buckets, cur, cur_bytes = [], [], 0
-    for p in params:
-        nb = p.grad.numel() * p.grad.element_size()
-        if cur and cur_bytes + nb > bucket_bytes:
-            buckets.append(cur)
-            cur, cur_bytes = [], 0
-        cur.append(p)
-        cur_bytes += nb
-    if cur:
-        buckets.append(cur)
-    pending = []
-    for b in buckets:
-        flat = torch.cat([p.grad.reshape(-1) for p in b])
-        pending.append((b, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)))
-    for b, flat, work in pending:
-        work.wait()
-        off = 0
-        for p in b:
-            n = p.grad.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
-
-
 class DataParallelStep:
     """One optimisation step of the XE (train.py:99-113) or SCST (train.py:151-178) phase on this rank's shard.
 

@@ -99,6 +99,10 @@ class SspEngine:
         S = roles.size(0)
         if roles.dim() != 2 or roles.size(1) != 10 or verbs.numel() != S:
             raise RuntimeError("expected verbs (S,) and roles (S,10); got %s and %s" % (tuple(verbs.shape), tuple(roles.shape)))
+        # the reference's embeddings raise IndexError for ids outside their tables (sort_model.py:108); the kernels would clamp
+        lo, hi = int(roles.min()), int(roles.max())
+        if lo < 0 or hi >= 26:
+            raise IndexError("semantic-role ids must lie in [0, 26) (0 = padding); got [%d, %d]" % (lo, hi))
         pred = torch.empty(S, 10, dtype=torch.int32, device=self.device)
         logp = torch.empty(S, 10, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
