@@ -17,6 +17,7 @@
 #include "gemm_bf16x3.h"
 #include "gemm_dma_variant.h"
 #include "ablate/gemm_f32x3.h"
+#error "the f32x3 variants 33xx of this tool are the product kernels of csrc/gemm_x3.h: build the ablation copy from the round-2 tree (git show 894f7fb:tools/gemm_bench.hip)"
 #include "ablate/gemm_bf16.h"
 #else
 #if defined(GEMM_STAMP) || defined(GEMM_PHASES) || defined(GEMM_ABLATE) || defined(X3_EXP) || defined(B16_ABLATE)
@@ -26,8 +27,8 @@
 #include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
 #include "gemm_bf16x3.h"
 #include "gemm_dma_variant.h"
-#include "../vsr-guided-cic_amd/csrc/gemm_f32x3.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_bf16.h"
+#include "../vsr-guided-cic_amd/csrc/gemm_x3.h"
 #endif
 
 using namespace vsr;
@@ -38,6 +39,12 @@ using namespace vsr;
 struct Twin { const float* f; size_t n; uint16_t* b; };
 static std::vector<Twin> g_twins;
 static bool g_bf16 = false, g_a16 = false;     // g_a16: variant 1665 = the bf16 kernel reading bf16 images of A (GemmSeg::A16)
+// f32x3 kernel (gemm_x3.h): variant "3300 <tm><tn>" with <tm><tn> = 22 (128 x 256 tile; also "1") or 21 (128 x 128)
+static bool is_x3(int tm) { return tm == 3300; }
+static void set_variant_globals(int tm) {
+    g_bf16 = tm == 1664 || tm == 1665;
+    g_a16 = tm == 1665;
+}
 
 static float* dev_rand(size_t n, unsigned seed) {
     std::vector<float> h(n);
@@ -81,12 +88,12 @@ struct Builder {
         if (tm == 2242) { bm = 256; bn = 128; }
         if (tm == 2142) { bm = 256; bn = 64; }
         if (tm == 2224) { bm = 128; bn = 256; }
-        if (tm == 3300) { bm = 128; bn = 256; }                                      // f32x3 kernel
+        if (is_x3(tm)) { bm = 128; bn = tn == 21 ? 128 : 256; }       // f32x3 kernel
         if (tm > 1600 && tm <= 1608) { bm = 16 * (tm - 1600); bn = 64 * tn; }      // rows-16 kernel: tm = 1600 + TM, tn = TN
         if (tm == 1664 || tm == 1665) { bm = 128; bn = 256; }                        // bf16 throughput kernel (bf16 W twins; 1665: bf16 A images too)
         int ns = 0;
         const bool b16 = tm == 1664 || tm == 1665;
-        if ((b16 || tm == 3300) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, b16 ? B16_BK : GEMM_BK);
+        if ((b16 || is_x3(tm)) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, b16 ? B16_BK : GEMM_BK);
         if (!ns) ns = gemm_plan(a, slots, min_iters, bm, bn, b16 ? B16_BK : GEMM_BK);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
         return ns;
@@ -96,7 +103,8 @@ struct Builder {
         dim3 g(((a.G + 7) / 8) * 8), b(256);
 #define R16(TM_) else if (tm == 1600 + TM_ && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 2>), g, dim3(512), 0, st, a); \
                  else if (tm == 1600 + TM_ && tn == 4) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 4>), g, dim3(512), 0, st, a);
-        if (tm == 3300) hipLaunchKernelGGL(gemm_nt_f32x3_kernel, g, dim3(X3_THREADS), 0, st, a);
+        if (is_x3(tm) && tn == 21) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), g, dim3(X3_THREADS), 0, st, a);
+        else if (is_x3(tm)) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), g, dim3(X3_THREADS), 0, st, a);
         else if (tm == 1664) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<false>, g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 1665) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<true>, g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
@@ -261,9 +269,8 @@ __global__ __launch_bounds__(512) void feed_kernel(const float* __restrict__ A, 
 // ---- fuzz: random ragged grouped launches (1-3 problems, 1-3 k segments each, row gathers, K tails, odd leading dimensions of C,
 // both work decompositions) of the variant under test against an fp64 host reference.  `tools/gemm_bench fuzz <tm> <tn> [cases] [seed]`
 static int fuzz(int tm, int tn, int cases, unsigned seed) {
-    g_bf16 = tm == 1664 || tm == 1665;
-    g_a16 = tm == 1665;
-    const bool wide = g_bf16 || tm == 3300;           // the 128 x 256 kernels: K multiples of 8 (bf16 chunks)
+    set_variant_globals(tm);
+    const bool wide = g_bf16 || is_x3(tm);            // the 16-wave kernels: K multiples of 8 (bf16 chunks)
     unsigned st = seed * 747796405u + 2891336453u;
     auto rnd = [&](int lo, int hi) { st = st * 1664525u + 1013904223u; return lo + (int)((st >> 8) % (unsigned)(hi - lo + 1)); };
     int bad = 0;
@@ -412,8 +419,7 @@ int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 500;
     const int slots = argc > 2 ? atoi(argv[2]) : 1024, min_iters = argc > 3 ? atoi(argv[3]) : 8;
     const int tm = argc > 4 ? atoi(argv[4]) : 1, tn = argc > 5 ? atoi(argv[5]) : 1;
-    g_bf16 = tm == 1664 || tm == 1665;
-    g_a16 = tm == 1665;
+    set_variant_globals(tm);
     // GEMM_ALIGNED=1: hidden sizes rounded to 1024 so that every row stride is a multiple of 128 B (cache-line aligned rows)
     const bool aligned = getenv("GEMM_ALIGNED") != nullptr;
     const int H = aligned ? 1024 : 1000, E = H, D = 2048, A = 512, V = 10000, in1 = H + D + E, in2 = H + D;
@@ -460,8 +466,7 @@ int main(int argc, char** argv) {
         std::vector<double> ref((size_t)m * n);
         for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < kk; ++k) s += (double)hA[(size_t)i * kk + k] * hW[(size_t)j * kk + k]; ref[(size_t)i * n + j] = s; }
         for (int variant = 0; variant < 2; ++variant) {
-            g_bf16 = variant && (tm == 1664 || tm == 1665);
-            g_a16 = variant && tm == 1665;
+            set_variant_globals(variant ? tm : 1);
             Builder b(slots, min_iters, variant ? tm : 1, variant ? tn : 1);
             GemmProb& p = b.prob(m, n, Cx, n); Builder::seg(p, A1, kk, nullptr, W, kk, kk);
             int ns = b.finish(); b.launch(0); CK(hipDeviceSynchronize());
@@ -472,8 +477,7 @@ int main(int argc, char** argv) {
         }
     }
 
-    g_bf16 = tm == 1664 || tm == 1665;
-    g_a16 = tm == 1665;
+    set_variant_globals(tm);
     // ---- timing on the decoder shapes
     float* h2 = dev_rand((size_t)M * H, 5); float* h1 = dev_rand((size_t)M * H, 6); float* att = dev_rand((size_t)M * D, 7);
     float* emb = dev_rand((size_t)V * E, 8);

@@ -1,20 +1,29 @@
-// "f32x3": fp32-accurate stream-K "NT" GEMM on the bf16 matrix cores.  OPTIONAL mode (model.set_compute_dtype('f32x3'),
-// bench.py --dtype f32x3); the default fp32 path stays the exact k-ordered fma chain of gemm_f32.h.
+// "f32x3": fp32-accurate "NT" GEMM on the bf16 matrix cores - the parity-mode default for launches the planner gives it.
 //
-// Both operands are fp32 in memory (no copies).  On its way into LDS every element x is split into three bf16 terms
+//   C_p[m][n] = sum over segments g, k:  A_pg[row_g(m)][k] * W_pg[n][k]        fp32 operands, fp32 accumulation, S partial slabs
+//
+// Every fp32 operand element x is three bf16 terms
 //     hi = bf16(x),  mid = bf16(x - hi),  lo = bf16(x - hi - mid)         (x = hi + mid + lo exactly: 3 x 8 = 24 mantissa bits)
-// and a product a.b is accumulated in fp32 as  hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid  (six
-// v_mfma_f32_32x32x16_bf16); the dropped terms mid.lo, lo.mid, lo.lo are <= 2^-23 of the product - the size of the ONE
-// rounding the fp32 fma chain commits per product.  Round 1 measured this split against fp64 at K = 1000: rms 5.0e-7 vs
-// 7.5e-7 for the fp32 chain.  It is NOT bit-identical to the chain (a different summation order, like any other fp32 GEMM):
-// the parity suite is what admits it (tests/test_gpu_f32x3.py: every token fixture, the 1e-4 loss bound, the gradient bounds).
+// and a product a.b is accumulated in fp32 as  lo.hi + hi.lo + mid.mid + mid.hi + hi.mid + hi.hi  (six v_mfma_f32_32x32x16_bf16,
+// smallest first); the dropped terms mid.lo, lo.mid, lo.lo are <= 2^-23 of the product - the size of the ONE rounding the fp32
+// fma chain commits per product (measured against fp64 at K = 1000: rms 4.0e-7 vs 5.9e-7 for the chain).  Not bit-identical to
+// the chain (a different summation order, like any other fp32 GEMM): the parity suite runs in both flavours (tests/conftest.py).
 //
-// Why: six bf16 MFMAs cost 6/16 of the fp32 MFMA time, so the kernel can afford the tile that halves the bytes per flop
-// (128 x 256 x 32, 43 flop per loaded byte against 21 for the fp32 kernel's 128 x 64) - the fp32 kernel is pinned at 0.65 of
-// its MFMA peak by the chip.  Structure = gemm_bf16.h: 16 waves (8 multiply 64 x 64 each, 8 move data), whole-line
-// loads, loads issued two tiles ahead, LDS-staged epilogue.  LDS: three bf16 planes of (128 + 256) rows x 32, rows unpadded
+// Both operands are fp32 in memory (no copies) and are split by the mover waves on their way into LDS.  Round 3 measured the
+// alternative the round-2 review asked for - operands that come as three bf16 PLANES in memory (weights split once per weight
+// version, activations by their producers), so that the movers only move: 6 bytes per element instead of 4 through the CU's
+// vector-memory path, which is what paces this kernel - and it was never faster (tools/gemm_bench, M = 500: 377 vs 357 us per
+// step's GEMMs at best, 688 us with stream-K ranges; M = 100: 114 vs 112 us).  Not kept; DESIGN.md section 4 has the table.
+//
+// Structure (gemm_bf16.h's): 16 waves - waves 0-7 MULTIPLY (WM x WN waves, TM x TN 32x32 tiles each), waves 8-15 MOVE data
+// (asynchronous global loads two k-tiles ahead -> split -> ds_write into the buffer the multipliers are not reading); one
+// barrier per k-tile.  Workgroup tile 128 x BN x 32 with BN = 256 (TM = TN = 2), 128 (TM 2, TN 1) or 64 (TM = TN = 1): the
+// narrow tiles exist for problems of <= 128 rows (greedy decoding, sampling, the per-step GEMMs of the training pass at batch
+// 100, a data-parallel shard): one m-tile holds every row, so the number of tiles is the number of n-tiles, and 256-wide tiles
+// would have to be cut into ~10 k pieces each to fill the CUs.  LDS: three bf16 planes of (128 + BN) rows x 32, rows unpadded
 // (64 bytes), 16-byte chunk c of row r at position c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 for the 32x32x16 operand
-// map), double buffered: 147 KB.
+// map), double buffered: 147 / 98 / 74 KB.  Work decomposition: stream-K ranges (gemm_plan) or k-aligned pieces
+// (gemm_plan_aligned); slab outputs; LDS-staged 16-byte epilogue stores.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,6 +34,7 @@ namespace vsr {
 
 constexpr int X3_BK = 32;
 constexpr int X3_ROW = 32;                               // bf16 elements per LDS row (64 bytes, unpadded, XOR-swizzled chunks)
+constexpr int X3_THREADS = 1024;
 
 // x -> (hi, mid, lo) for two values at once: three packed bf16 pairs
 __device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
@@ -36,20 +46,17 @@ __device__ __forceinline__ void split3(float a, float b, uint32_t& hi, uint32_t&
     lo = pack_bf16(ar - am, br - bm);
 }
 
-// 16 waves per workgroup, like gemm_bf16.h: waves 0-7 MULTIPLY (2 x 4, 64 x 64 per wave, two per SIMD), waves 8-15 MOVE data
-// (asynchronous global loads two k-tiles ahead, the three-way split, ds_write into the buffer the multipliers are not reading);
-// one barrier per k-tile.  With one kind of wave (this file's first version, 8 waves) a k-tile cost
-// [load wait + split + LDS refill] + [18 ds_read + 24 MFMA per k-step] = 3.3 us; the ablations (tools/ablate/) put 175 us of MFMA next to
-// 195 us of split / load / LDS time per decoder step, and those now overlap.
-constexpr int X3_THREADS = 1024;
+constexpr size_t x3_lds_bytes(int TM, int TN) { return (size_t)2 * 3 * (128 + 32 * TN * (8 / (4 / TM))) * X3_ROW * sizeof(uint16_t); }
+
+template <int TM, int TN>
 __global__ __launch_bounds__(X3_THREADS)
-void gemm_nt_f32x3_kernel(const GemmArgs args) {
-    constexpr int WN = 4, TM = 2, TN = 2;                  // multipliers: 2 x 4 waves, wave tile 64 x 64
-    constexpr int BM = 128, BN = 256, BK = X3_BK;
-    constexpr int LA = BM / 64, LB = BN / 64;              // movers: 512 threads cover 64 rows of a k-tile per pass
+void gemm_nt_x3_kernel(const GemmArgs args) {
+    constexpr int WM = 4 / TM, WN = 8 / WM;                // multipliers: WM x WN = 8 waves
+    constexpr int BM = 128, BN = 32 * TN * WN, BK = X3_BK;
+    static_assert(32 * TM * WM == BM, "tile shape");
     constexpr int PLANE = (BM + BN) * X3_ROW;             // bf16 elements per plane
     constexpr int BUF = 3 * PLANE;                        // hi | mid | lo
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];           // 147 KB of the CU's 160 KB: one workgroup per CU
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];
 
     const int G = args.G;
     const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
@@ -90,6 +97,8 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
         return kt;
     };
 
+    // Epilogue of one tile piece: bands of 32 tile rows are staged in a k buffer by the multiplier waves that own them and leave
+    // as 16-byte row stores issued by all 1024 threads; unused slabs of a finished tile get zeros the same way.
     constexpr int ST_LD = BN + 4;
     static_assert(32 * ST_LD * 4 <= BUF * 2, "staging band must fit one k buffer");
     f32x16 acc[TM][TN];
@@ -99,14 +108,15 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
         float* C = P.C + (long long)c_piece * P.slab_stride;
         const int extra = c_last ? args.nslab - 1 - c_piece : 0;
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
-        constexpr int TPR = BN / 4;
-        constexpr int RPP = X3_THREADS / TPR;
+        constexpr int TPR = BN / 4;                        // threads per staged row
+        constexpr int RPP = X3_THREADS / TPR;              // rows per store pass (16 / 32 / 64)
         const int c4 = (tid % TPR) * 4;
         const int n = n0 + c4;
         const int wm = wave / WN, wn = wave % WN;          // (multipliers)
         wait_loads<0>();                                   // stores share vmcnt with the asynchronous loads: start from an empty queue
 #pragma unroll
         for (int band = 0; band < BM / 32; ++band) {
+            if (m0 + band * 32 >= P.M) break;              // rows past the problem (a short m-tile): nothing to stage or store
             if constexpr (decltype(MULT)::value) {
 #pragma unroll
                 for (int ti = 0; ti < TM; ++ti)
@@ -120,10 +130,10 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
             }
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 32 / RPP; ++i) {
+            for (int i = 0; i < (32 + RPP - 1) / RPP; ++i) {
                 const int sr = tid / TPR + RPP * i;
                 const int m = m0 + band * 32 + sr;
-                if (m < P.M && n < P.N) {
+                if (sr < 32 && m < P.M && n < P.N) {
                     const float4 v = *reinterpret_cast<const float4*>(stage + sr * ST_LD + c4);
                     float* dst = C + (long long)m * P.ldc + n;
                     if (vec_ok && n + 3 < P.N) {
@@ -164,7 +174,8 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
     if (mover) {
         // ================================================================================================ movers
         const int ptid = tid - 512;
-        const int lrow = ptid >> 3, lk = (ptid & 7) * 4;   // 8 lanes x float4 cover a row's k-tile (one 128-byte line)
+        const int lrow = ptid >> 3, lk = (ptid & 7) * 4;   // 8 lanes x float4 cover a row's k-tile (one 128-byte line), 64 rows per pass
+        constexpr int LA = BM / 64, LB = BN / 64;          // loads per thread and k-tile
         f32x4_t ra[2][LA], rb[2][LB];                      // tile j (counted from it0) lives in register set j & 1
         bool stl[2] = {false, false};
         const float* pa[LA];
@@ -172,8 +183,10 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
         int l_prob = 0, l_tile = 0, l_tile_left = 0;
         int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0;
         auto open_segment = [&](int sg, int first_tile) __attribute__((always_inline)) {
-            const GemmProb& P = args.p[l_prob];
-            const GemmSeg& S = P.seg[sg];
+            // (readfirstlane: the indices are wave-uniform, but hipcc cannot always prove it and then copies the whole argument
+            // struct to scratch to index it per lane)
+            const GemmProb& P = args.p[__builtin_amdgcn_readfirstlane(l_prob)];
+            const GemmSeg& S = P.seg[__builtin_amdgcn_readfirstlane(sg)];
             const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
             l_seg = sg;
             l_K = S.K;
@@ -327,7 +340,5 @@ void gemm_nt_f32x3_kernel(const GemmArgs args) {
         }
     }
 }
-
-constexpr size_t X3_LDS_BYTES = (size_t)2 * 3 * (128 + 256) * X3_ROW * sizeof(uint16_t);
 
 }  // namespace vsr

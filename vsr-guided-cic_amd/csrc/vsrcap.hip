@@ -26,7 +26,7 @@
 
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
-#include "gemm_f32x3.h"
+#include "gemm_x3.h"
 #include "kernels.h"
 #include "train_kernels.h"
 
@@ -116,7 +116,14 @@ struct vsr_handle {
     int gemm_slots = 1024;       // resident 64x64 GEMM workgroups to fill: 256 CUs x 4 (36.9 KB LDS each)
     int gemm_slots_small = 768;  // 64x64 tiles (M <= 192): 3 per CU measured best (greedy 473 k vs 461 k tokens/s at 4 per CU)
     int gemm_min_iters = 8;
-    int gemm_x3_min_rows = 193;  // f32x3 flavour: launches with fewer rows stay on the exact kernels (VSR_X3_MIN_ROWS)
+    int gemm_x3_min_rows = 193;  // f32x3 flavour: launches of at least this many rows take the 128 x 256 tile (VSR_X3_MIN_ROWS)
+    int x3_skinny = 1;           // ... launches of r16_max < rows <= 128 the 128 x 128 tile (one m-tile holds every row; VSR_X3_SKINNY=0: exact kernels)
+    // k-aligned pieces (gemm_plan_aligned) when the tiles fit the CUs, else stream-K ranges.  VSR_X3_ALIGNED=<wide><skinny> as two digits;
+    // wide: 0 never, 1 always, 2 from 1024 rows up.  Measured end to end: beam-5 (M = 500) 265.7 k tokens/s with stream-K ranges against
+    // 256.5 k with aligned pieces; XE step (its wide launches have 2000 rows) 9.52 k against 9.40 k samples/s; greedy (M = 100) 572 k
+    // with aligned pieces against 550 k with stream-K ranges
+    int x3_aligned_wide = 2, x3_aligned_skinny = 1;
+    int x3_aligned_min = 4;      // shortest k-aligned piece of the f32x3 kernels, in 32-wide k-tiles
     int gemm_slots_r16 = 256;    // rows-16 kernel: ONE 8-wave workgroup per CU (two waves per SIMD)
     // Problems with at most this many rows take the rows-16 kernel (VSR_GEMM_R16_MAX=0 disables it).  Measured end to end on
     // one MI355X: at M = 100 it is level with the 64x64 kernel inside a GEMM (61.5 vs 60.6 TF/s) but its tiles are cut into
@@ -124,7 +131,7 @@ struct vsr_handle {
     // padding saves (greedy 459 k vs 481 k tokens/s, XE step 6.8 k vs 7.4 k samples/s).  Below 64 rows (a data-parallel
     // shard of 12-13 images and its 65 beam rows, small eval batches) the 64-row tiles are mostly padding and the rows-16 kernel wins
     // (M = 13: 19.5 vs 13.2 TF/s over the four step GEMMs; beam-5 over a 13-image shard, M = 65: 3.48 vs 3.81 ms per call).
-    int gemm_r16_max = 80;
+    int gemm_r16_max = 40;
     int bf16_a16 = 1;            // bf16 mode: the decode step's producers write bf16 images of the GEMM A operands (VSR_BF16_A16=0: off)
     int gemm_aligned = 1;        // 128 x 256 kernels: k-aligned pieces (gemm_plan_aligned) when the tiles fit the CUs; VSR_GEMM_ALIGNED=0: stream-K always
     int gemm_aligned_min = 8;    // shortest piece, in 64-wide k-tiles (VSR_GEMM_ALIGNED_MIN)
@@ -239,6 +246,7 @@ struct GemmBuilder {
     }
     int big = 0;       // 2: 128x128 workgroup tiles, 1: 128x64, 0: 64x64 (32x32x2 MFMA); 16: rows-16 kernel (16x16x4 MFMA), r16_tm tiles
     int r16_tm = 0;
+    int x3_tn = 2;       // f32x3 kernel: workgroup tile 128 x 256 (2) or 128 x 128 (1)
     bool a16_all = false;   // bf16 kernel: every segment's A operand has a bf16 image (GemmSeg::A16)
     bool stale_w = false;   // bf16 mode: a W operand exists only as a bf16 image but the launch does not qualify for the bf16 kernel
     // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
@@ -278,7 +286,12 @@ struct GemmBuilder {
             }
         }
         big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM >= 1024 ? 2 : maxM > 192 ? 1 : 0);
-        if (h->x3_on && maxM >= h->gemm_x3_min_rows) {        // below that the 128 x 256 tile has too few tiles (measured slower than the exact kernels at M = 100)
+        if (h->x3_on && h->gemm_tile == 0) {
+            // f32x3 (gemm_x3.h): 128 x 256 tiles from 193 rows up; 128 x 128 tiles for launches whose rows fit ONE m-tile (greedy
+            // decoding, sampling, the per-step GEMMs of the training pass at batch 100, a shard of a strong-scaled decode): the
+            // number of tiles is then the number of n-tiles, which 256-wide tiles would have to cut into ~10 k pieces each.
+            // Measured over the four step GEMMs (tools/gemm_bench): M = 100: 112 us against 160 us for the exact 64 x 64 kernel;
+            // M = 65: 107 against 120 (rows-16) / 154; M = 13: 100 against 64 for the rows-16 kernel, which keeps the shortest launches.
             bool ok = true;
             for (int i = 0; i < a.nprob && ok; ++i)
                 for (int sg = 0; sg < a.p[i].nseg && ok; ++sg) {
@@ -286,9 +299,15 @@ struct GemmBuilder {
                     ok = (S.K % 4 == 0) && (S.ldw % 4 == 0) && (S.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(S.W) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(S.A) & 15) == 0);
                 }
-            if (ok) {
-                big = 33;                              // (stream-K: this kernel is bound by its multipliers, the k-aligned plan's idle CUs cost more than its L2 hits save: 137 vs 121 us on S1)
-                return gemm_plan(a, h->gemm_slots_bf16, 4, 128, 256, X3_BK);
+            const bool wide = ok && maxM >= h->gemm_x3_min_rows;
+            const bool skinny = ok && !wide && h->x3_skinny && maxM <= 128 && maxM > h->gemm_r16_max;
+            if (wide || skinny) {
+                big = 33;
+                x3_tn = wide ? 2 : 1;
+                const int BN = wide ? 256 : 128;
+                if (wide ? (h->x3_aligned_wide == 1 || (h->x3_aligned_wide == 2 && maxM >= 1024)) : h->x3_aligned_skinny != 0)
+                    if (const int ns = gemm_plan_aligned(a, h->gemm_slots_bf16, h->x3_aligned_min, 128, BN, X3_BK)) return ns;
+                return gemm_plan(a, h->gemm_slots_bf16, 4, 128, BN, X3_BK);
             }
         }
         if (h->gemm_tile == 0 && maxM <= h->gemm_r16_max) {
@@ -312,7 +331,8 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : big == 33 ? X3_THREADS : big == 16 ? 512 : 256);
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
-    if (big == 33) hipLaunchKernelGGL(gemm_nt_f32x3_kernel, grid, block, 0, s, a);
+    if (big == 33 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), grid, block, 0, s, a);
+    else if (big == 33) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), grid, block, 0, s, a);
     else if (big == 32 && a16_all) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<true>, grid, block, 0, s, a);
     else if (big == 32) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<false>, grid, block, 0, s, a);
     else if (big == 16) {
@@ -367,6 +387,9 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
         h->gemm_slots_bf16 = prop.multiProcessorCount;
     }
     if (const char* e = getenv("VSR_X3_MIN_ROWS")) h->gemm_x3_min_rows = atoi(e);
+    if (const char* e = getenv("VSR_X3_SKINNY")) h->x3_skinny = atoi(e);
+    if (const char* e = getenv("VSR_X3_ALIGNED")) { h->x3_aligned_wide = atoi(e) / 10; h->x3_aligned_skinny = atoi(e) % 10; }
+    if (const char* e = getenv("VSR_X3_ALIGNED_MIN")) h->x3_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_BF16")) h->gemm_slots_bf16 = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_R16")) h->gemm_slots_r16 = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_R16_MAX")) h->gemm_r16_max = atoi(e);
