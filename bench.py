@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the VSR captioning decoder hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload beam5|beam5idx|greedy|xe|scst]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload beam5|beam5idx|greedy|xe|xeidx|scst]
                     [--scaling weak|strong] [--dtype f32x3|f32|bf16] [--no-cpu] [--no-secondary] [--no-alt]
 
 Headline (BASELINE.json metric, configs[2]): beam-5 decode through ControllableCaptioningModel.beam_search, batch 100
@@ -374,14 +374,21 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
     m, weights = make_model(torch, synth, dev, True, args.dtype)
     opt = torch.optim.Adam(m.parameters(), lr=5e-4, fused=True)      # train.py:77 Adam(lr=5e-4); one fused launch per step
     xe = args.workload != "scst"
+    indexed = args.workload == "xeidx"          # index-list regions on the training path: slot entries name detection rows
     strong = args.scaling == "strong" and world > 1
     lo, hi = parallel.shard_bounds(c["B"], world, rank) if strong else (0, c["B"])
     L = c["T"] if xe else c["L"]
     batches = []
     for i in range(2):
         seed = 2000 + i + (0 if strong else 10 * rank)
-        batches.append((torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev),
-                        torch.from_numpy(synth.make_ctrl(c["B"], L, c["R"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev),
+        if indexed:
+            from vsrcap.regions import IndexedRegions
+            det = torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed, min_valid=c["R0"])[lo:hi]).contiguous().to(dev)
+            reg = IndexedRegions(det, torch.from_numpy(synth.make_slot_indices(c["B"], L, c["R"], c["R0"], seed=seed)[lo:hi]).contiguous().to(dev))
+        else:
+            det = torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev)
+            reg = torch.from_numpy(synth.make_ctrl(c["B"], L, c["R"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev)
+        batches.append((det, reg,
                         torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed)[lo:hi]).contiguous().to(dev),
                         torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed)[lo:hi]).contiguous().to(dev)))
     step = parallel.DataParallelStep(m, opt, forward_fn=lambda d, cp, sq: m((d,), (cp, sq)),
@@ -427,7 +434,7 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
     dt = D.max_time(dt)
     images = c["B"] if strong else world * c["B"]
     line = {
-        "metric": "XE-step samples/sec" if xe else "SCST-step images/sec (5 samples/image + greedy baseline, CIDEr-D rewards on device)",
+        "metric": ("XE-step samples/sec" + (", index-list region format" if indexed else "")) if xe else "SCST-step images/sec (5 samples/image + greedy baseline, CIDEr-D rewards on device)",
         "value": images * steps / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
@@ -450,7 +457,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="beam5", choices=["beam5", "beam5idx", "greedy", "xe", "scst"])
+    ap.add_argument("--workload", default="beam5", choices=["beam5", "beam5idx", "greedy", "xe", "xeidx", "scst"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--dtype", default="f32x3", choices=["f32", "f32x3", "bf16"],
                     help="f32x3 = parity mode (headline): fp32 operands, fp32 accumulation, products of launches > 192 rows from three bf16 "
@@ -478,7 +485,7 @@ def main():
     if args.gpus != D.world and D.rank == 0:
         print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, D.world, D.world), file=sys.stderr)
 
-    if args.workload in ("xe", "scst"):
+    if args.workload in ("xe", "xeidx", "scst"):
         line, weights = train_bench(args, D, torch, dist, synth, args.steps, args.warmup)
         if D.rank == 0 and D.world == 1 and not args.no_cpu and args.workload == "xe":
             line["cpu_baseline"] = cpu_baseline_xe(weights, min(args.cpu_sample, 16), torch, synth)

@@ -152,8 +152,11 @@ def test_indexed_errors_are_loud():
         m.test(det, regions.IndexedRegions(reg.bank, torch.cat([reg.slot_idx, reg.slot_idx], 0)))
     caps = torch.from_numpy(synth.make_captions(2, cfg["L"], cfg["V"], seed=1)).to(DEV)
     m.train()
-    with pytest.raises(RuntimeError, match="decode-side format"):
-        m((det,), (caps, reg))
+    if reg.row_img is None:                                    # one row per image: index lists train (tests/test_gpu_train_indexed.py)
+        out, _ = m((det,), (caps, reg))
+        assert out.requires_grad
+    with pytest.raises(RuntimeError, match="one decoder row per image"):
+        m((det,), (caps, regions.IndexedRegions(reg.bank, reg.slot_idx, torch.arange(reg.slot_idx.size(0), dtype=torch.int32, device=DEV))))
     m.eval()
     with torch.no_grad():                                      # the handle is usable again after the failures
         w1, _ = m.test(det, reg)

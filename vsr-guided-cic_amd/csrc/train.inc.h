@@ -26,6 +26,7 @@ struct TrainCtx {
     float *gates1, *gates2, *s_ts, *g_ts, *hAs, *sas, *gas, *sents, *atts, *alphas, *x_all;
     int *word32, *slot32, *rows_bt;
     float *dlogits, *dh2_voc, *dpre1, *dpre2, *dhA_all, *dsent_all, *dsa_all, *dga_all, *dwa_rows, *dws_rows, *dwg_rows, *dP;
+    float* dP_bank = nullptr;        // index-list regions: dP summed over the slot entries that name each bank row
     float *dalpha;
     float *datt, *dtc, *dh_tot, *dzsum, *dh1_c, *dh2_c, *dc1_c[2], *dc2_c[2], *dpre1sum, *dpre2sum, *dx_all;
     float *wT_ih1, *wT_is, *wT_ig, *wT_hh1, *wT_hs, *wT_ih2, *wT_hh2, *wT_hg, *wT_ha, *wT_sfc, *wT_sa, *wT_ga, *wT_out;
@@ -49,7 +50,9 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     const Ctx& c = h->c;
     const size_t B = t.B, T = t.T, H = d.rnn_size, A = d.att_size, D = d.det_feat_size, E = d.input_encoding_size, V = d.vocab_size;
     const size_t in1 = (d.h2_first_lstm ? H : 0) + D + E, in2 = H + D + (d.img_second_lstm ? D : 0);
-    const size_t TB = T * B, TBp = up4(TB), Bp = up4(B), RL = (size_t)c.B * c.L * c.R, RLp = up4(RL), R1 = c.R + 1;
+    const size_t TB = T * B, TBp = up4(TB), Bp = up4(B), RL = (size_t)c.B * c.L * c.R, R1 = c.R + 1;
+    // rows att_va's weight gradient runs over: the slot entries (dense regions) or the feature-bank rows (index lists)
+    const size_t PR = c.Rb > 0 ? (size_t)c.n_img * c.Rb : RL, RLp = up4(std::max(RL, PR));
     t.TB = (int)TB; t.TBp = (int)TBp; t.Bp = (int)Bp; t.RLp = (int)RLp;
     Bump b{base};
     t.h1s = b.take<float>((T + 1) * B * H); t.c1s = b.take<float>((T + 1) * B * H);
@@ -65,6 +68,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.dhA_all = b.take<float>(TB * A); t.dsent_all = b.take<float>(TB * D); t.dsa_all = b.take<float>(TB * A); t.dga_all = b.take<float>(TB * A);
     t.dwa_rows = b.take<float>(TB * A); t.dws_rows = b.take<float>(TB * A); t.dwg_rows = b.take<float>(TB * A);
     t.dP = b.take<float>(RL * A);
+    t.dP_bank = c.Rb > 0 ? b.take<float>(PR * A) : nullptr;
     t.datt = b.take<float>(B * D); t.dtc = b.take<float>(B * H);
     t.dh_tot = b.take<float>(B * H); t.dzsum = b.take<float>(B); t.dalpha = b.take<float>(B * R1);
     t.dh1_c = b.take<float>(B * H); t.dh2_c = b.take<float>(B * H);
@@ -156,7 +160,9 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     if (!word_in || !logp_words || !logp_gates || !train_ws) return fail("vsr_train_forward: null tensor");
     Ctx& c = h->c;
     if (c.beam != 1 && c.Mmax != c.B) return fail("vsr_train_forward: prepare() must be called with beam = 1");
-    if (c.ridx) return fail("vsr_train_forward: index-list regions (vsr_prepare_indexed) are a decode-side format; train on dense region tensors (vsr_prepare)");
+    // index-list regions (vsr_prepare_indexed) train too, with one decoder row per image (the XE / SCST batches of train.py: every
+    // sample brings its own detections): the backward pass sums dP over the entries of a row that name the same bank row
+    if (c.ridx && !c.rows_are_images) return fail("vsr_train_forward: index-list regions with a row -> image map (row_img) are a decode-side format; training needs one row per image (row_img = NULL)");
     if (!slots && (T < 1 || T > c.L)) return fail("vsr_train_forward: without a slot trace step t reads slot t: need 1 <= T <= L (T %d, L %d)", T, c.L);
     hipStream_t s = (hipStream_t)stream;
     const vsr_dims& d = h->d;
@@ -251,9 +257,9 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         }
         {
             const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
-            if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
+            if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx, slot, 0, 1, B, c.L,
                                c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
-            else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, (const int*)nullptr, slot, 0, 1, B, c.L,
+            else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx, slot, 0, 1, B, c.L,
                                c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
         }
         {   // S5
@@ -444,11 +450,11 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         // attention
         {
             const size_t smem = (size_t)(R1 + 8) * sizeof(float);
-            hipLaunchKernelGGL(k_dalpha, dim3(cdiv((long long)B * R1, 4)), dim3(256), 0, s, t.datt, sent, c.regions, c.rmask, slot, B, c.L, c.R, D,
+            hipLaunchKernelGGL(k_dalpha, dim3(cdiv((long long)B * R1, 4)), dim3(256), 0, s, t.datt, sent, c.regions, c.rmask, c.ridx, slot, B, c.L, c.R, D,
                                t.dalpha);
-            if (A >= 512) hipLaunchKernelGGL(k_attend_bwd<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask,
+            if (A >= 512) hipLaunchKernelGGL(k_attend_bwd<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx,
                                slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws);
-            else hipLaunchKernelGGL(k_attend_bwd<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask,
+            else hipLaunchKernelGGL(k_attend_bwd<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx,
                                slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws);
         }
         // grouped GEMM 2: [dq | dhA] -> dh1_b ; [dsent | dsa] -> ds_t;  then the sentinel gate and LSTM1 pointwise backward
@@ -512,7 +518,14 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     transpose(h, s, t.dsent_all, D, TB, D, t.tY_dsent, TBp);
     transpose(h, s, t.dsa_all, A, TB, A, t.tY_dsa, TBp);
     transpose(h, s, t.dga_all, A, TB, A, t.tY_dga, TBp);
-    if (NV > 0) transpose(h, s, t.dP, (long long)A, NV, A, t.tY_dP, (long long)NVp, c.vlist);
+    const float* dP_rows = t.dP;
+    if (c.ridx) {
+        // index lists: several slot entries of an image name the same bank row; att_va's gradient runs over bank rows, so the
+        // entry gradients are first summed per bank row, in ascending entry order (deterministic, like the embedding gradient)
+        hipLaunchKernelGGL(k_dP_to_bank, dim3(c.n_img * c.Rb), dim3(128), 0, s, t.dP, c.ridx, c.L * c.R, c.Rb, A, t.dP_bank);
+        dP_rows = t.dP_bank;
+    }
+    if (NV > 0) transpose(h, s, dP_rows, (long long)A, NV, A, t.tY_dP, (long long)NVp, c.vlist);
     hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 6 * H, 256)), dim3(256), 0, s, t.dpre1, T, (long long)B * 6 * H, t.dpre1sum);
     transpose(h, s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
     LAUNCHCHK();

@@ -155,6 +155,33 @@ __global__ __launch_bounds__(256) void k_embed_grad_rows(const float* __restrict
     }
 }
 
+// Index-list regions (data/field.py:44-61 as indices): dP_bank[row] = sum of the entry gradients dP[e] over the slot
+// entries e of the row's image that name bank row `row`, IN ASCENDING e (deterministic).  One workgroup per bank row, one float4
+// column group per thread (A <= 512 per pass); the image's entry list (L R ints) is scanned 64 entries at a time.
+__global__ __launch_bounds__(128) void k_dP_to_bank(const float* __restrict__ dP, const int* __restrict__ ridx, int LR, int Rb, int A,
+                                                    float* __restrict__ dP_bank) {
+    const int row = blockIdx.x, img = row / Rb, tid = threadIdx.x, lane = tid & 63;
+    const int* e_idx = ridx + (long long)img * LR;
+    const float* src = dP + (long long)img * LR * A;
+    for (int a0 = 0; a0 < A; a0 += 512) {
+        const int a = a0 + tid * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = 0; c0 < LR; c0 += 64) {
+            const int j = c0 + lane;
+            unsigned long long m = __ballot(j < LR && e_idx[j] == row);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (a < A) {
+                    const float4 v = *reinterpret_cast<const float4*>(src + (long long)(c0 + b) * A + a);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            }
+        }
+        if (a < A) *reinterpret_cast<float4*>(dP_bank + (long long)row * A + a) = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- forward saves
 // LSTM1 + gates, training flavour: also stores the post-activation gates (B, 6H) = [i f g o s_gate .]
 __global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ vproj,
@@ -225,6 +252,7 @@ __global__ __launch_bounds__(256) void k_fwd_tail(const GateLogitArgs gl, int gb
 // over D, so that a training batch of 100 rows still fills the chip (one workgroup per row left 60 % of the CUs idle).
 __global__ __launch_bounds__(256) void k_dalpha(const float* __restrict__ datt, const float* __restrict__ sent,
                                                 const float* __restrict__ X, const float* __restrict__ rmask,
+                                                const int* __restrict__ ridx /* index-list regions: bank row of every slot entry, or null */,
                                                 const int* __restrict__ slot, int M, int L, int R, int D, float* __restrict__ dalpha) {
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= M * (R + 1)) return;
@@ -233,7 +261,7 @@ __global__ __launch_bounds__(256) void k_dalpha(const float* __restrict__ datt, 
     float s = 0.f;
     if (j == 0 || rmask[sl * R + j - 1] != 0.f) {
         const float* g = datt + (long long)row * D;
-        const float* src = (j == 0) ? sent + (long long)row * D : X + (sl * R + j - 1) * D;
+        const float* src = (j == 0) ? sent + (long long)row * D : X + (ridx ? (long long)ridx[sl * R + j - 1] : sl * R + j - 1) * D;
         float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
         int d = lane * 4;
         for (; d + 768 < D; d += 1024) {
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_attend_bwd(const float* __restrict__ dat
                                                     const float* __restrict__ alpha, const float* __restrict__ hA,
                                                     const float* __restrict__ sa, const float* __restrict__ sent,
                                                     const float* __restrict__ P, const float* __restrict__ X,
-                                                    const float* __restrict__ rmask, const int* __restrict__ slot, int fixed_slot,
+                                                    const float* __restrict__ rmask, const int* __restrict__ ridx, const int* __restrict__ slot, int fixed_slot,
                                                     int M, int L, int R, int A, int D, const float* __restrict__ w_a,
                                                     const float* __restrict__ w_s, float* __restrict__ dsent, float* __restrict__ dsa,
                                                     float* __restrict__ dhA, float* __restrict__ dP, float* __restrict__ dwa_rows,
@@ -326,7 +354,7 @@ __global__ __launch_bounds__(NT) void k_attend_bwd(const float* __restrict__ dat
             for (int q = 0; q < 8; ++q) {
                 const int r = r0 + q;
                 const bool live = r < R && da[r + 1] != 0.f;            // uniform over the workgroup
-                pv[q] = live ? Pk[(long long)r * A + a] : 0.f;
+                pv[q] = live ? (ridx ? P[(long long)ridx[sl * R + r] * A + a] : Pk[(long long)r * A + a]) : 0.f;
                 dpv[q] = live ? dPk[(long long)r * A + a] : 0.f;
             }
 #pragma unroll

@@ -53,6 +53,7 @@ struct Ctx {
     const float* det = nullptr;
     const float* regions = nullptr;   // dense (B, L, R, D) region tensor, or the (n_img, Rb, D) feature bank
     const int* ridx = nullptr;   // (B, L, R) absolute bank row per slot entry (index-list format) or null
+    bool rows_are_images = false;   // index-list format without a row -> image map: decoder row b owns bank rows [b Rb, (b + 1) Rb) (training needs this)
     int* ridx_buf = nullptr;
     float* bmask = nullptr;      // row masks of the rows att_va runs over (dense: = rmask)
     float* dmask = nullptr;      // row masks of the detection rows (pooled descriptor)
@@ -621,6 +622,7 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     const size_t need = carve(h, c, reinterpret_cast<char*>(workspace));
     if (need > workspace_bytes) return fail("%s: workspace too small (%zu < %zu bytes)", who, workspace_bytes, need);
     c.ridx = c.ridx_buf;
+    c.rows_are_images = indexed && row_img == nullptr && n_img == B;
     h->prepared = false;
     invalidate_train_ctx(h->tc);       // a saved forward refers to the hoisted tensors of the previous prepare()
 

@@ -166,7 +166,7 @@ class ControllableCaptioningModel(CaptioningModel):
 
     def _prepare(self, eng, det, regions, beam):
         """Hoisted per-image work for either region format: the reference's dense (B,L,R,D) tensor, or
-        vsrcap.regions.IndexedRegions (index lists into the image's feature bank; decode only)."""
+        vsrcap.regions.IndexedRegions (index lists into the image's feature bank; training too when every row is its own image)."""
         from vsrcap.regions import IndexedRegions
         if isinstance(regions, IndexedRegions):
             return eng.prepare_indexed(det, regions.bank, regions.slot_idx, regions.row_img, beam, self._weights_version())
@@ -180,9 +180,10 @@ class ControllableCaptioningModel(CaptioningModel):
             raise RuntimeError("captions longer than seq_len")
         from vsrcap.regions import IndexedRegions
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if isinstance(ctrl_seq, IndexedRegions):
-                raise RuntimeError("IndexedRegions is a decode-side format: train on the dense region tensor (regions.dense())")
-            B = eng.prepare(det, ctrl_seq, 1, self._weights_version())
+            if isinstance(ctrl_seq, IndexedRegions) and ctrl_seq.row_img is not None:
+                raise RuntimeError("training on IndexedRegions needs one decoder row per image (row_img=None), as the reference's "
+                                   "training batches have; with a row -> image map train on regions.dense()")
+            B = self._prepare(eng, det, ctrl_seq, 1)
             from vsrcap.train import xe_forward_with_grad
             return xe_forward_with_grad(self, eng, det, captions, ctrl_seq)
         B = self._prepare(eng, det, ctrl_seq, 1)
@@ -205,8 +206,8 @@ class ControllableCaptioningModel(CaptioningModel):
         eng = self._engine(det.device)
         from vsrcap.regions import IndexedRegions
         with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if with_grad and isinstance(ctrl, IndexedRegions):
-            raise RuntimeError("IndexedRegions is a decode-side format: sample with gradients on the dense region tensor")
+        if with_grad and isinstance(ctrl, IndexedRegions) and ctrl.row_img is not None:
+            raise RuntimeError("sample_rl with gradients on IndexedRegions needs one decoder row per image (row_img=None)")
         B = self._prepare(eng, det, ctrl, 1)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())

@@ -1,4 +1,4 @@
-"""Index-list region format: the decode-side wire format of SURVEY 8f N2.
+"""Index-list region format: the wire format of SURVEY 8f N2 (decode, and training when every decoder row is its own image).
 
 The reference's callers hand the decoder a dense (rows, L, R, D) float tensor that is nothing but copies of rows of the
 image's detection-feature matrix (`data/field.py:44-61`, `coco_scripts/eval_coco.py:222-247`).  Here the same information
@@ -37,7 +37,7 @@ class IndexedRegions:
         return IndexedRegions(self.bank.to(device), self.slot_idx.to(device), None if self.row_img is None else self.row_img.to(device))
 
     def dense(self):
-        """The (B, L, R, D) tensor the reference would have been given (tests, and the training path, which is dense)."""
+        """The (B, L, R, D) tensor the reference would have been given (tests; training with a row -> image map)."""
         B, L, R = self.slot_idx.shape
         img = self.row_img.long() if self.row_img is not None else torch.arange(B, device=self.slot_idx.device)
         idx = self.slot_idx.long()

@@ -55,7 +55,7 @@ def sample_logprobs_with_grad(model, eng, det, ctrl, outs, lps):
     (word fed at step t = previous sample, slot pointer = clamped running sum of the previous gates)."""
     words, gates = outs
     B, T = words.shape
-    L = ctrl.size(1)
+    L = ctrl.size(1)                      # (dense tensor or IndexedRegions: both answer size(1) with the slot count)
     bos = torch.full((B, 1), model.bos_idx, dtype=torch.int64, device=words.device)
     word_in = torch.cat([bos, words[:, :-1]], 1)
     slots = torch.cat([torch.zeros_like(bos), torch.clamp(torch.cumsum(gates[:, :-1], 1), max=L - 1)], 1)
