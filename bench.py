@@ -392,7 +392,8 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
                         torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed)[lo:hi]).contiguous().to(dev),
                         torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed)[lo:hi]).contiguous().to(dev)))
     step = parallel.DataParallelStep(m, opt, forward_fn=lambda d, cp, sq: m((d,), (cp, sq)),
-                                     sample_fn=lambda d, ct: m.sample_rl(d, ct), all_reduce_fn=D.all_reduce_fn())
+                                     sample_fn=lambda d, ct: m.sample_rl(d, ct), all_reduce_fn=D.all_reduce_fn(),
+                                     exchange_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     NS = 5                          # samples per image (BASELINE configs[4]); the reference has no such loop, the caller
     rl_batches = []                 # repeats every image NS times
     if not xe:
@@ -443,7 +444,7 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
                                ("SCST step: greedy baseline (100 images) + sample_rl on 500 rows (5 samples/image) + replayed forward + BPTT "
                                 "backward + Adam(fused=True), rewards = device CIDEr-D vs synthetic references, 10 slots x 36 x 2048 (BASELINE configs[4])"),
                    "batch_per_gpu": hi - lo, "seq_len": c["T"],
-                   "parallelism": "dp%d, %s gradient all-reduce in buckets on a side stream, overlapped with the weight-gradient GEMMs" % (world, "RCCL" if args.backend == "nccl" else "gloo (self-test, host-staged)"),
+                   "parallelism": "dp%d, %s gradient all-reduce (%s on the wire) in buckets on a side stream, overlapped with the weight-gradient GEMMs" % (world, "RCCL" if args.backend == "nccl" else "gloo (self-test, host-staged)", "bf16, 142 MB" if args.dtype == "bf16" else "fp32, 285 MB"),
                    "rccl_world_size_observed": D.observed_world()},
         "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, gemm_bytes=gemm_bytes),
     }

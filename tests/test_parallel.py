@@ -107,3 +107,47 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
     # the gate targets really have a data-dependent number of ignored entries per shard
     lo, hi = parallel.shard_bounds(cfg["B"], 2, 0)
     assert (gts[lo:hi] == -1).sum() != (gts[hi:] == -1).sum()
+
+
+# ---- bf16 wire format of the gradient exchange (BASELINE configs[3]: "bf16 ... RCCL grad all-reduce"): fp32 gradients are rounded to
+# bf16 only for the collective; the summed result goes back into the fp32 buffer the optimizer reads
+def _worker_bf16(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg = CFG
+    det, seq, caps, gts = helpers.train_inputs(cfg, 9)
+    lo, hi = parallel.shard_bounds(cfg["B"], world, rank)
+    out = {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        o, params = _make(cfg)
+        opt = torch.optim.SGD(params, lr=0.0)           # lr 0: the step leaves the exchanged gradients in .grad for inspection
+
+        def host_sum(t):                                # gloo's own bf16 support varies by build: sum in fp32 what the wire carried
+            c = t.float()
+            dist.all_reduce(c)
+            t.copy_(c)
+        step = parallel.DataParallelStep(params, opt, forward_fn=lambda d, c, s: o.forward(d, c, s), exchange_dtype=dt,
+                                         all_reduce_fn=host_sum if dt == torch.bfloat16 else None)
+        step.xe_step(det[lo:hi], caps[lo:hi], seq[lo:hi], gts[lo:hi])
+        out[name] = torch.cat([p.grad.reshape(-1) for p in params]).clone()
+    if rank == 0:
+        ret["f32"], ret["bf16"] = out["f32"].numpy(), out["bf16"].numpy()
+    dist.destroy_process_group()
+
+
+def test_bf16_gradient_exchange_rounds_only_the_wire():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_bf16, args=(2, _free_port(), ret), nprocs=2, join=True)
+    a, b = ret["f32"], ret["bf16"]
+    assert not np.array_equal(a, b), "the bf16 wire format was not used"
+    # each rank's share is rounded to 8 mantissa bits (relative 2^-9 per term) and the sum once more
+    scale = np.abs(a).max()
+    assert np.abs(a - b).max() <= 3 * 2.0 ** -9 * scale
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+    assert cos > 0.99999, cos
+    # every exchanged value is exactly representable in bf16 (the wire carried bf16 and the host sum was rounded back)
+    bt = torch.from_numpy(b)
+    assert torch.equal(bt.bfloat16().float(), bt)
