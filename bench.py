@@ -197,7 +197,7 @@ class Dist:
             return None
 
         def host(t):
-            c = t.detach().cpu()
+            c = t.detach().float().cpu()          # (a bf16 wire buffer is summed in fp32 here: gloo's bf16 support varies by build)
             self.dist.all_reduce(c)
             t.copy_(c)
         return host
