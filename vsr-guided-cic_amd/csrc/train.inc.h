@@ -35,8 +35,6 @@ struct TrainCtx {
     float* xproj_all;            // (T B, 6H): embedding rows through the x columns of the LSTM1 / gate input weights
     float* scratch;
     size_t scratch_floats = 0;
-    char* tpad_begin = nullptr;        // transposed-activation region (zeroed when its rows are padded)
-    size_t tpad_bytes = 0;
     // bf16 mode: every transposed operand that a GEMM takes as W (transposed weights, transposed activations of the
     // weight-gradient products) has a bf16 twin the transposing kernels write instead of the fp32 buffer
     struct Twin { const float* f; size_t n; uint16_t* b; };
@@ -85,7 +83,6 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     twin(t.wT_ih2, in2 * 4 * H); twin(t.wT_hh2, H * 4 * H); twin(t.wT_hg, H * H); twin(t.wT_ha, H * A); twin(t.wT_sfc, H * D);
     twin(t.wT_sa, H * A); twin(t.wT_ga, H * A); twin(t.wT_out, H * up4(V));
     b.off = (b.off + 255) & ~size_t(255);
-    const size_t tp0 = b.off;
     t.tX_h2prev = b.take<float>(H * TBp); t.tX_x = b.take<float>(E * TBp); t.tX_h1prev = b.take<float>(H * TBp);
     t.tX_h1 = b.take<float>(H * TBp); t.tX_att = b.take<float>(D * TBp); t.tX_st = b.take<float>(H * TBp);
     t.tX_gt = b.take<float>(H * TBp); t.tX_h2 = b.take<float>(H * TBp); t.tX_vbar = b.take<float>(D * Bp);
@@ -95,8 +92,6 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.tY_dpre1sum = b.take<float>(6 * H * Bp); t.tY_dpre2sum = b.take<float>(4 * H * Bp); t.tY_dP = b.take<float>(A * RLp);
     twin(t.tX_h2prev, H * TBp); twin(t.tX_x, E * TBp); twin(t.tX_h1prev, H * TBp); twin(t.tX_h1, H * TBp); twin(t.tX_att, D * TBp);
     twin(t.tX_st, H * TBp); twin(t.tX_gt, H * TBp); twin(t.tX_h2, H * TBp); twin(t.tX_vbar, D * Bp); twin(t.tX_reg, D * RLp);
-    t.tpad_begin = base ? base + tp0 : nullptr;
-    t.tpad_bytes = b.off - tp0;
     // GEMM slab scratch: 8 slabs of the largest product of the training path
     size_t big = std::max({4 * H * in1, V * H, 4 * H * in2, A * D, TB * H, TB * E, D * H, B * (in2 + 2 * H), H * in1, TB * V, TB * 6 * H});
     t.scratch_floats = big * 8;
@@ -387,7 +382,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     HIPCHK(hipMemsetAsync(t.dc1_c[0], 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dc2_c[0], 0, BH * sizeof(float), s));
     const int NV = c.nvalid, NVp = (int)up4((size_t)NV);     // non-padding region rows: the only ones att_va saw
-    if (TBp != TB || Bp != B || NVp != NV) HIPCHK(hipMemsetAsync(t.tpad_begin, 0, t.tpad_bytes, s));
+    // (the K padding of the transposed operands - TBp, Bp, NVp columns - is zero-filled by the transposing kernel itself)
 
     // ---- phase 0: dlogits (t,b) and the vocabulary part of dh2 for every step
     hipLaunchKernelGGL(k_dlogits_tb, dim3(TB), dim3(256), 0, s, t.logp_w, grad_logp_words, B, T, V, Vp, t.dlogits);

@@ -64,10 +64,15 @@ __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ i
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             } else {
+                // (columns R .. ld_out - 1 are the K padding of the GEMM that reads this operand - fewer than 8: zeros, written here
+                // instead of a memset of the whole transposed region per step)
                 for (int e = 0; e < 4; ++e)
                     if (r + e < R) {
                         if (BF16) out16[(long long)c * ld_out + r + e] = to_bf16_bits(v[e]);
                         else dst[e] = v[e];
+                    } else if (r + e < ld_out) {
+                        if (BF16) out16[(long long)c * ld_out + r + e] = 0;
+                        else dst[e] = 0.f;
                     }
             }
         }

@@ -119,10 +119,10 @@ struct vsr_handle {
     int gemm_min_iters = 8;
     int gemm_x3_min_rows = 193;  // f32x3 flavour: launches of at least this many rows take the 128 x 256 tile (VSR_X3_MIN_ROWS)
     int x3_skinny = 1;           // ... launches of r16_max < rows <= 128 the 128 x 128 tile (one m-tile holds every row; VSR_X3_SKINNY=0: exact kernels)
-    // k-aligned pieces (gemm_plan_aligned) when the tiles fit the CUs, else stream-K ranges.  VSR_X3_ALIGNED=<wide><skinny> as two digits;
-    // wide: 0 never, 1 always, 2 from 1024 rows up.  Measured end to end: beam-5 (M = 500) 265.7 k tokens/s with stream-K ranges against
-    // 256.5 k with aligned pieces; XE step (its wide launches have 2000 rows) 9.52 k against 9.40 k samples/s; greedy (M = 100) 572 k
-    // with aligned pieces against 550 k with stream-K ranges
+    // k-aligned pieces (gemm_plan_aligned) or stream-K ranges.  VSR_X3_ALIGNED=<wide><skinny> as two digits; wide: 0 never, 1 whenever the
+    // tiles fit the CUs, 2 (default) per launch by its efficiency (GemmBuilder::finish) and always from 1024 rows up.  Measured end to
+    // end: beam-5 (M = 500) 265.7 k tokens/s with stream-K ranges everywhere against 256.5 k with aligned pieces everywhere; XE step
+    // (its wide launches have 2000 rows) 9.52 k against 9.40 k samples/s; greedy (M = 100) 572 k with aligned pieces against 550 k
     int x3_aligned_wide = 2, x3_aligned_skinny = 1;
     int x3_aligned_min = 4;      // shortest k-aligned piece of the f32x3 kernels, in 32-wide k-tiles
     int gemm_slots_r16 = 256;    // rows-16 kernel: ONE 8-wave workgroup per CU (two waves per SIMD)
@@ -304,11 +304,38 @@ struct GemmBuilder {
             const bool skinny = ok && !wide && h->x3_skinny && maxM <= 128 && maxM > h->gemm_r16_max;
             if (wide || skinny) {
                 big = 33;
-                x3_tn = wide ? 2 : 1;
-                const int BN = wide ? 256 : 128;
-                if (wide ? (h->x3_aligned_wide == 1 || (h->x3_aligned_wide == 2 && maxM >= 1024)) : h->x3_aligned_skinny != 0)
-                    if (const int ns = gemm_plan_aligned(a, h->gemm_slots_bf16, h->x3_aligned_min, 128, BN, X3_BK)) return ns;
-                return gemm_plan(a, h->gemm_slots_bf16, 4, 128, BN, X3_BK);
+                const int slots = h->gemm_slots_bf16;
+                // efficiency of a k-aligned plan: work units over (slots x longest piece); 1 = every CU busy for the whole launch
+                auto aligned_eff = [&](GemmArgs& g) {
+                    int T = 1;
+                    for (int i = 0; i < g.nprob; ++i) T = std::max(T, (g.p[i].ktiles + g.p[i].split - 1) / g.p[i].split);
+                    return (double)g.total_iters / ((double)slots * T);
+                };
+                if (skinny) {
+                    x3_tn = 1;
+                    if (h->x3_aligned_skinny)
+                        if (const int ns = gemm_plan_aligned(a, slots, h->x3_aligned_min, 128, 128, X3_BK)) return ns;
+                    return gemm_plan(a, slots, 4, 128, 128, X3_BK);
+                }
+                // Wide launches: stream-K ranges keep every CU busy but cut a tile into 3-5 pieces (slabs every consumer has to add);
+                // k-aligned pieces share their k-windows in L2 and write exactly `split` slabs, but leave CUs idle when tiles x split
+                // does not fill the chip.  Measured on the beam-5 step shapes (tools/gemm_bench, M = 500): S2 (64 tiles of K = 1000)
+                // 42 us / 5 slabs with stream-K ranges, 35 us / 2 slabs with k-aligned halves of 128 x 128 tiles; S5 125 us / 5 slabs
+                // vs 124 us / 3 slabs (efficiency 0.76); S1 120 vs 137 us (0.74); the vocabulary GEMM 82 vs 88 us (0.63).
+                if (h->x3_aligned_wide != 0) {
+                    const bool force = h->x3_aligned_wide == 1 || maxM >= 1024;
+                    GemmArgs a22 = a, a21 = a;
+                    const int ns22 = gemm_plan_aligned(a22, slots, h->x3_aligned_min, 128, 256, X3_BK);
+                    int tiles22 = 0;
+                    for (int i = 0; i < a.nprob; ++i) tiles22 += ((a.p[i].M + 127) / 128) * ((a.p[i].N + 255) / 256);
+                    if (tiles22 <= 64 && maxM < 1024) {              // a small launch: halves of narrow tiles fill the chip with fewer slabs
+                        const int ns21 = gemm_plan_aligned(a21, slots, h->x3_aligned_min, 128, 128, X3_BK);
+                        if (ns21 && aligned_eff(a21) >= 0.95 && (!ns22 || ns21 < ns22)) { a = a21; x3_tn = 1; return ns21; }
+                    }
+                    if (ns22 && (force || aligned_eff(a22) >= 0.75)) { a = a22; x3_tn = 2; return ns22; }
+                }
+                x3_tn = 2;
+                return gemm_plan(a, slots, 4, 128, 256, X3_BK);
             }
         }
         if (h->gemm_tile == 0 && maxM <= h->gemm_r16_max) {
