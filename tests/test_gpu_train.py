@@ -141,3 +141,43 @@ def test_optimizer_step_stays_visible_to_the_library():
         oopt.step()
         ol.append(l.item())
     np.testing.assert_allclose(losses, ol, atol=2e-4, rtol=0)
+
+
+def test_bucketed_exchange_is_ordered_behind_the_gradients_it_carries(monkeypatch):
+    """The overlapped exchange of DataParallelStep on ONE GPU (round-2 advisor finding): every gradient bucket is handed to an
+    ASYNCHRONOUS device operation on the side stream behind the library's bucket event (vsr_train_wait_bucket).  With "all-reduce"
+    = multiply by 2 (a stand-in with an exactly known result), every one of the 28 gradients must come out as exactly twice the
+    gradient of a step without exchange: a bucket exchanged before one of its gradients was complete would leave that gradient
+    undoubled (or half-written); so would a gradient assigned to the wrong bucket.  Also: the same through the bf16 wire format."""
+    from vsrcap import parallel
+    meta, _ = load_golden("g1_xe_wide")
+    cfg = meta["cfg"]
+    w = helpers.weights_for(cfg, gains=meta["gains"])
+    det, ctrl_seq, caps, gts = (x.to(DEV) for x in helpers.train_inputs(cfg, meta["seed"]))
+    m = helpers.build_model(cfg, w, DEV).train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)                    # lr 0: the gradients stay inspectable, the weights fixed
+
+    def grads_of(step):
+        step.xe_step(det, caps, ctrl_seq, gts)
+        torch.cuda.synchronize()
+        return [v.clone() for v in step.grads.views]
+
+    plain = parallel.DataParallelStep(m, opt, forward_fn=lambda d, c, s: m((d,), (c, s)))
+    ref = grads_of(plain)
+    plain.close()
+    calls = []
+
+    def doubling(buf):                                               # asynchronous device work on the (side) stream it is called on
+        calls.append(buf.numel())
+        buf.mul_(2.0)
+    for dt in (torch.float32, torch.bfloat16):
+        calls.clear()
+        st = parallel.DataParallelStep(m, opt, forward_fn=lambda d, c, s: m((d,), (c, s)), all_reduce_fn=doubling, exchange_dtype=dt)
+        monkeypatch.setattr(st, "_world", lambda: 2)
+        monkeypatch.setattr(st, "_sum", lambda t: t)                 # the loss statistics need no second rank here
+        got = grads_of(st)
+        assert len(calls) == st.n_buckets and sum(calls) == st.grads.flat.numel()
+        for i, (a, b) in enumerate(zip(got, ref)):
+            want = 2.0 * (b.bfloat16().float() if dt == torch.bfloat16 else b)
+            assert torch.equal(a, want), "gradient %d (bucket order) differs from twice the plain gradient" % i
+        st.close()

@@ -560,9 +560,10 @@ extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t byte
     if (!h) return fail("vsr_refresh_bf16_weights: null handle");
     if (!buffer) {                                          // back to the fp32 parity mode
         h->bf16_on = false;
-        h->b16.resize(0);
+        h->b16.erase(h->b16.begin(), h->b16.begin() + h->b16_weights);     // the weight copies only: the training workspace's twins stay registered
         h->b16_weights = 0;
         h->xproj = nullptr;                                 // a decode cache built in the other precision is void
+        invalidate_train_ctx(h->tc);                        // a saved forward of the other precision cannot be differentiated in this one
         return 0;
     }
     if (!h->bound) return fail("vsr_refresh_bf16_weights: weights not bound");
