@@ -26,9 +26,14 @@ bf16)
   done
   python tools/hbm_traffic.py $OUT/pmc16_FETCH_SIZE $OUT/pmc16_WRITE_SIZE $OUT/gemm_bf16_hbm_traffic.json gemm_nt_bf16w
   find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
-x3)
-  VSR_COMPUTE_DTYPE=f32x3 timeout 1500 python -m pytest tests -m gpu -q -rA --deselect tests/test_gpu_bf16.py > $OUT/pytest_f32x3.log 2>&1; echo "pytest(f32x3) rc=$?" >> $OUT/pytest_f32x3.log; tail -5 $OUT/pytest_f32x3.log
-  for w in beam5 greedy xe; do timeout 300 python bench.py --workload $w --dtype f32x3 --no-cpu --no-secondary --no-alt > $OUT/bench_${w}_f32x3.json 2> $OUT/bench_${w}_f32x3.err; cat $OUT/bench_${w}_f32x3.json; done ;;
+f32)
+  for w in beam5 greedy xe; do timeout 300 python bench.py --workload $w --dtype f32 --no-cpu --no-secondary --no-alt > $OUT/bench_${w}_f32.json 2> $OUT/bench_${w}_f32.err; cat $OUT/bench_${w}_f32.json; done ;;
+idx)
+  for w in beam5idx xeidx; do timeout 300 python bench.py --workload $w --no-cpu --no-secondary --no-alt > $OUT/bench_${w}.json 2> $OUT/bench_${w}.err; cat $OUT/bench_${w}.json; done ;;
+b13)
+  timeout 300 python bench.py --batch 13 --no-cpu --no-secondary --no-alt > $OUT/bench_beam5_batch13.json 2> $OUT/bench_beam5_batch13.err; cat $OUT/bench_beam5_batch13.json
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_batch13 -- python3 $GRAFT_REPO_ROOT/bench.py --batch 13 --steps 20 --warmup 3 --no-cpu --no-secondary --no-alt > $GRAFT_REPO_ROOT/$OUT/stats_batch13.log 2>&1)
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
 stats)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_beam5 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu --no-secondary --no-alt > $GRAFT_REPO_ROOT/$OUT/stats_beam5.log 2>&1)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_xe -- python3 $GRAFT_REPO_ROOT/bench.py --workload xe --steps 5 --warmup 2 --no-cpu > $GRAFT_REPO_ROOT/$OUT/stats_xe.log 2>&1)
@@ -39,8 +44,9 @@ pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --no-alt > $GRAFT_REPO_ROOT/$OUT/pmc_$c.log 2>&1)
   done
-  python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/gemm_hbm_traffic.json gemm_
+  python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/gemm_f32x3_hbm_traffic.json gemm_nt_x3
   python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/attend_hbm_traffic.json k_attend
+  python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/vocab_hbm_traffic.json k_vocab
   find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;
 esac
 done

@@ -587,7 +587,10 @@ extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t byte
     h->b16_weights = h->b16.size();
     h->b16.insert(h->b16.end(), keep.begin(), keep.end());
     LAUNCHCHK();
-    if (!h->bf16_on) h->xproj = nullptr;
+    if (!h->bf16_on) {
+        h->xproj = nullptr;
+        invalidate_train_ctx(h->tc);                        // (as above: the GEMM precision of a saved forward and its backward must match)
+    }
     h->bf16_on = true;
     return 0;
 }
