@@ -317,6 +317,8 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
             }
         }
         const int ns = b.finish();
+        const bool tight = rnd(0, 1);                       // per-problem slab counts (gemm_tight_slabs): only those slabs are summed below
+        if (tight) for (int p = 0; p < nprob; ++p) b.a.p[p].nslab = gemm_tight_slabs(b.a, p);
         b.launch(0);
         CK(hipDeviceSynchronize());
         double worst = 0, scale = 0;
@@ -335,7 +337,7 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
                         for (int k = 0; k < h.K[sg]; ++k) ref += (double)a[k] * w[k];
                     }
                     double got = 0;
-                    for (int q = 0; q < ns; ++q) got += hC[(size_t)q * h.M * h.ldc + (size_t)i * h.ldc + h.coff + j];
+                    for (int q = 0; q < b.a.p[p].nslab; ++q) got += hC[(size_t)q * h.M * h.ldc + (size_t)i * h.ldc + h.coff + j];
                     worst = fmax(worst, fabs(got - ref));
                 }
             scale = fmax(scale, sqrt((double)ktot) * 0.083);      // |a| |w| ~ U(-0.5, 0.5): products ~ 1/12 rms

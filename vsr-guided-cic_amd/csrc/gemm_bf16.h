@@ -137,7 +137,7 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
         const GemmProb& P = args.p[c_prob];
         const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
         float* C = P.C + (long long)c_piece * P.slab_stride;
-        const int extra = c_last ? args.nslab - 1 - c_piece : 0;     // unused slabs of a finished tile: zeros
+        const int extra = c_last ? P.nslab - 1 - c_piece : 0;     // unused slabs of a finished tile: zeros
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
         constexpr int TPR = BN / 4;                        // 64 threads per staged row
         constexpr int RPP = B16_THREADS / TPR;             // 16 rows per store pass

@@ -56,6 +56,7 @@ struct GemmProb {
     int it_begin;        // first global iteration of this problem
     int g_begin;         // aligned plan only: first workgroup of this problem ...
     int split;           // ... and the number of equal k pieces every one of its tiles is cut into
+    int nslab;           // slabs THIS problem's tiles write (<= GemmArgs::nslab): its consumers add exactly these
 };
 
 struct GemmArgs {
@@ -247,7 +248,7 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
         int m0, n0;
         gemm_tile_origin(P, c_tile, BM, BN, m0, n0);
         float* C = P.C + (long long)c_piece * P.slab_stride;
-        const int extra = c_last ? args.nslab - 1 - c_piece : 0;     // unused slabs of a finished tile: zeros
+        const int extra = c_last ? P.nslab - 1 - c_piece : 0;     // unused slabs of a finished tile: zeros
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
         constexpr int TPR = BN / 4;                        // threads per staged row
         constexpr int RPP = NT / TPR;                      // rows per store pass
@@ -503,7 +504,7 @@ void gemm_nt_f32_r16_kernel(const GemmArgs args) {
         const GemmProb& P = args.p[c_prob];
         const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
         float* C = P.C + (long long)c_piece * P.slab_stride;
-        const int extra = c_last ? args.nslab - 1 - c_piece : 0;
+        const int extra = c_last ? P.nslab - 1 - c_piece : 0;
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
         constexpr int TPR = BN / 4;                        // threads per staged row
         constexpr int RPP = NT / TPR;                      // rows per store pass
@@ -663,6 +664,7 @@ inline int gemm_plan(GemmArgs& a, int slots, int min_iters = 8, int BM = 64, int
     const int L = total / G;                       // shortest range
     a.nslab = G == 1 ? 1 : (kt_max + L - 1) / L + 1;
     if (a.nslab > 8) a.nslab = 8;
+    for (int i = 0; i < a.nprob; ++i) a.p[i].nslab = a.nslab;      // (gemm_tight_slabs: fewer for a short-K problem of a merged launch)
     a.aligned = 0;
     return a.nslab;
 }
@@ -714,8 +716,21 @@ inline int gemm_plan_aligned(GemmArgs& a, int slots, int min_iters, int BM, int 
     a.total_iters = total;
     a.G = g;
     a.nslab = nslab;
+    for (int i = 0; i < a.nprob; ++i) a.p[i].nslab = nslab;       // every problem writes / zero-fills the launch's slab count (gemm_tight_slabs: its own split)
     a.aligned = 1;
     return nslab;
+}
+
+// Slabs problem i of a planned launch really needs: a tile of k k-tiles meets at most ceil(k / L) + 1 stream-K ranges of at least L
+// iterations (k-aligned plan: exactly its split).  A caller whose consumer reads problem i on its own may lower GemmProb::nslab to
+// this (the kernel then writes / zero-fills that many slabs for the problem, the consumer adds that many): the vocabulary GEMM that
+// shares a launch with the LSTM1 sums of the next step, att_ga next to LSTM2.
+inline int gemm_tight_slabs(const GemmArgs& a, int i) {
+    if (a.aligned) return a.p[i].split;
+    if (a.G <= 1) return 1;
+    const int L = a.total_iters / a.G;
+    const int ns = (a.p[i].ktiles + L - 1) / L + 1;
+    return ns < a.nslab ? ns : a.nslab;
 }
 
 inline double gemm_flops(const GemmArgs& a) {

@@ -106,7 +106,7 @@ void gemm_nt_x3_kernel(const GemmArgs args) {
         const GemmProb& P = args.p[c_prob];
         const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
         float* C = P.C + (long long)c_piece * P.slab_stride;
-        const int extra = c_last ? args.nslab - 1 - c_piece : 0;
+        const int extra = c_last ? P.nslab - 1 - c_piece : 0;
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
         constexpr int TPR = BN / 4;                        // threads per staged row
         constexpr int RPP = X3_THREADS / TPR;              // rows per store pass (16 / 32 / 64)

@@ -882,12 +882,14 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         const long long stride = (long long)M * 4 * H, stride_g = (long long)M * A;
         g.a.p[0].slab_stride = stride;
         g.a.p[1].C = c.ga_slabs; g.a.p[1].slab_stride = stride_g;
+        g.a.p[1].nslab = gemm_tight_slabs(g.a, 1);
         if (g.launch(s, h)) return fail("S5 gemm launch failed");
         hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
                            w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n, h2n16);
         // the gate logits (z_g, log_softmax([z_g, zsum]), step :185-188) are nobody's input before the selection: the
         // vocabulary kernel's row blocks compute them on the side instead of a launch of their own
-        gate_args = GateLogitArgs{c.ga_slabs, ns, stride_g, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A,
+        // (att_ga has a quarter of LSTM2's K: fewer stream-K pieces per tile, fewer slabs for the gate logits to add)
+        gate_args = GateLogitArgs{c.ga_slabs, g.a.p[1].nslab, stride_g, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A,
                                   io.lg_out, io.lg_stride};
     }
     // ---- S6
@@ -916,8 +918,11 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[0].slab_stride = stride;
         for (int i = 1; i < g.a.nprob; ++i) g.a.p[i].slab_stride = (long long)M * 6 * H;
         c.pre1_ns = ns; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
+        // the vocabulary tiles (K = H) are cut into fewer pieces than the LSTM1 tiles (K = 2 H) they share the launch with: k_vocab
+        // adds only the slabs they wrote (60 -> 40 MB of logits per beam-5 step)
+        const int ns_vocab = g.a.p[0].nslab = gemm_tight_slabs(g.a, 0);
         if (g.launch(s, h)) return fail("S6 gemm launch failed");
-#define VOCAB_ARGS c.scratch, ns, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
+#define VOCAB_ARGS c.scratch, ns_vocab, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
                    io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row, gate_args, c.nvalid_dev + 2
         const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;          // combined logits row staged in LDS (<= 96 KB)
         const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
