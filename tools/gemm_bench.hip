@@ -90,7 +90,7 @@ struct Builder {
         if (tm == 2224) { bm = 128; bn = 256; }
         if (is_x3(tm)) { bm = 128; bn = tn == 21 ? 128 : 256; }       // f32x3 kernel
         if (tm > 1600 && tm <= 1608) { bm = 16 * (tm - 1600); bn = 64 * tn; }      // rows-16 kernel: tm = 1600 + TM, tn = TN
-        if (tm == 1664 || tm == 1665) { bm = 128; bn = 256; }                        // bf16 throughput kernel (bf16 W twins; 1665: bf16 A images too)
+        if (tm == 1664 || tm == 1665) { bm = 128; bn = tn == 21 ? 128 : 256; }       // bf16 throughput kernel (bf16 W twins; 1665: bf16 A images too); tn 21: 128 x 128 tile
         int ns = 0;
         const bool b16 = tm == 1664 || tm == 1665;
         if ((b16 || is_x3(tm)) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, b16 ? B16_BK : GEMM_BK);
@@ -105,8 +105,10 @@ struct Builder {
                  else if (tm == 1600 + TM_ && tn == 4) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 4>), g, dim3(512), 0, st, a);
         if (is_x3(tm) && tn == 21) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), g, dim3(X3_THREADS), 0, st, a);
         else if (is_x3(tm)) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), g, dim3(X3_THREADS), 0, st, a);
-        else if (tm == 1664) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<false>, g, dim3(B16_THREADS), 0, st, a);
-        else if (tm == 1665) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<true>, g, dim3(B16_THREADS), 0, st, a);
+        else if (tm == 1664 && tn == 21) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 1>), g, dim3(B16_THREADS), 0, st, a);
+        else if (tm == 1665 && tn == 21) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<true, 1>), g, dim3(B16_THREADS), 0, st, a);
+        else if (tm == 1664) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 2>), g, dim3(B16_THREADS), 0, st, a);
+        else if (tm == 1665) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<true, 2>), g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
         R16(1) R16(2) R16(3) R16(4) R16(5) R16(6) R16(7) R16(8)
         else if (tm == 322) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2>), g, b, 0, st, a);

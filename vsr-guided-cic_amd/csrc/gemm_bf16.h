@@ -76,11 +76,13 @@ __device__ __forceinline__ void landed(u32x4_t& d) { asm volatile("" : "+v"(d));
 // A16K: every segment's A operand comes with a bf16 image (GemmSeg::A16, written by A's producer): the movers load 8 bf16 per
 // lane and store them as they are - half the A bytes, no conversion.  Otherwise A is fp32 and converted on the way into LDS.
 constexpr int B16_THREADS = 1024;
-template <bool A16K>
+// TN = 2: workgroup tile 128 x 256; TN = 1: 128 x 128, for launches whose rows fit one m-tile (the recurrent GEMMs of the training
+// pass at batch 100, greedy decoding): the number of tiles is then the number of n-tiles (as in gemm_x3.h, round 3)
+template <bool A16K, int TN = 2>
 __global__ __launch_bounds__(B16_THREADS)
 void gemm_nt_bf16w_kernel(const GemmArgs args) {
-    constexpr int WN = 4, TM = 2, TN = 2;                  // multipliers: 2 x 4 waves, wave tile 64 x 64
-    constexpr int BM = 128, BN = 256, BK = B16_BK;
+    constexpr int WN = 4, TM = 2;                          // multipliers: 2 x 4 waves, wave tile 64 x 32 TN
+    constexpr int BM = 128, BN = 32 * TN * WN, BK = B16_BK;
     constexpr int LA = BM / 32, LB = BN / 64;              // movers: 512 threads cover 32 A rows / 64 W rows per pass
     constexpr int BUF = (BM + BN) * B16_ROW;               // bf16 elements per k buffer
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];
@@ -140,7 +142,7 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
         const int extra = c_last ? P.nslab - 1 - c_piece : 0;     // unused slabs of a finished tile: zeros
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
         constexpr int TPR = BN / 4;                        // 64 threads per staged row
-        constexpr int RPP = B16_THREADS / TPR;             // 16 rows per store pass
+        constexpr int RPP = B16_THREADS / TPR;             // 16 / 32 rows per store pass
         const int c4 = (tid % TPR) * 4;
         const int n = n0 + c4;
         const int wm = wave / WN, wn = wave % WN;          // (multipliers)

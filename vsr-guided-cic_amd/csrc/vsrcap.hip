@@ -247,7 +247,7 @@ struct GemmBuilder {
     }
     int big = 0;       // 2: 128x128 workgroup tiles, 1: 128x64, 0: 64x64 (32x32x2 MFMA); 16: rows-16 kernel (16x16x4 MFMA), r16_tm tiles
     int r16_tm = 0;
-    int x3_tn = 2;       // f32x3 kernel: workgroup tile 128 x 256 (2) or 128 x 128 (1)
+    int x3_tn = 2;       // f32x3 and bf16 kernels: workgroup tile 128 x 256 (2) or 128 x 128 (1)
     bool a16_all = false;   // bf16 kernel: every segment's A operand has a bf16 image (GemmSeg::A16)
     bool stale_w = false;   // bf16 mode: a W operand exists only as a bf16 image but the launch does not qualify for the bf16 kernel
     // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
@@ -281,9 +281,12 @@ struct GemmBuilder {
                         a16_all = a16_all && S.A16 && (S.lda % 8 == 0) && ((reinterpret_cast<uintptr_t>(S.A16) & 15) == 0);
                     }
                 big = 32;
+                // launches whose rows fit one m-tile: 128 x 128 tiles (twice the tiles, half the k pieces per tile), as for f32x3
+                x3_tn = (h->x3_skinny && maxM <= 128) ? 1 : 2;
+                const int BN = x3_tn == 1 ? 128 : 256;
                 if (h->gemm_aligned)
-                    if (const int ns = gemm_plan_aligned(a, h->gemm_slots_bf16, h->gemm_aligned_min, 128, 256, B16_BK)) return ns;
-                return gemm_plan(a, h->gemm_slots_bf16, 4, 128, 256, B16_BK);
+                    if (const int ns = gemm_plan_aligned(a, h->gemm_slots_bf16, x3_tn == 1 ? 2 : h->gemm_aligned_min, 128, BN, B16_BK)) return ns;
+                return gemm_plan(a, h->gemm_slots_bf16, 4, 128, BN, B16_BK);
             }
         }
         big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM >= 1024 ? 2 : maxM > 192 ? 1 : 0);
@@ -361,8 +364,10 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
     if (big == 33 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 33) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), grid, block, 0, s, a);
-    else if (big == 32 && a16_all) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<true>, grid, block, 0, s, a);
-    else if (big == 32) hipLaunchKernelGGL(gemm_nt_bf16w_kernel<false>, grid, block, 0, s, a);
+    else if (big == 32 && a16_all && x3_tn == 1) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<true, 1>), grid, block, 0, s, a);
+    else if (big == 32 && x3_tn == 1) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 1>), grid, block, 0, s, a);
+    else if (big == 32 && a16_all) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<true, 2>), grid, block, 0, s, a);
+    else if (big == 32) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 2>), grid, block, 0, s, a);
     else if (big == 16) {
         switch (r16_tm) {
             case 1: hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<1, 2>), grid, block, 0, s, a); break;
