@@ -29,6 +29,7 @@
 #include "gemm_dma_variant.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_bf16.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_x3.h"
+#include "../vsr-guided-cic_amd/csrc/gemm_x3s.h"
 #endif
 
 using namespace vsr;
@@ -89,6 +90,13 @@ struct Builder {
         if (tm == 2142) { bm = 256; bn = 64; }
         if (tm == 2224) { bm = 128; bn = 256; }
         if (is_x3(tm)) { bm = 128; bn = tn == 21 ? 128 : 256; }       // f32x3 kernel
+        if (tm == 3400) {                                                            // weight-streaming f32x3 kernel (<= 128 rows): "3400 <MT or 0 = by M>", k-aligned pieces only
+            const int mi = getenv("GEMM_PLAN_ALIGNED") ? atoi(getenv("GEMM_PLAN_ALIGNED")) : 8;
+            int ns = gemm_plan_aligned(a, slots, mi, 128, x3s_bn(getenv("X3S_NS") ? atoi(getenv("X3S_NS")) : 2), X3_BK);
+            if (!ns) { printf("x3s: the 64-column blocks of this launch exceed %d slots\n", slots); exit(1); }
+            for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
+            return ns;
+        }
         if (tm > 1600 && tm <= 1608) { bm = 16 * (tm - 1600); bn = 64 * tn; }      // rows-16 kernel: tm = 1600 + TM, tn = TN
         if (tm == 1664 || tm == 1665) { bm = 128; bn = tn == 21 ? 128 : 256; }       // bf16 throughput kernel (bf16 W twins; 1665: bf16 A images too); tn 21: 128 x 128 tile
         int ns = 0;
@@ -103,7 +111,22 @@ struct Builder {
         dim3 g(((a.G + 7) / 8) * 8), b(256);
 #define R16(TM_) else if (tm == 1600 + TM_ && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 2>), g, dim3(512), 0, st, a); \
                  else if (tm == 1600 + TM_ && tn == 4) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 4>), g, dim3(512), 0, st, a);
-        if (is_x3(tm) && tn == 21) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), g, dim3(X3_THREADS), 0, st, a);
+        if (tm == 3400) {
+            int maxM = 0; for (int i = 0; i < a.nprob; ++i) maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
+            const int mt = tn > 1 && tn <= 8 ? tn : (maxM + 15) / 16;
+            const bool ns1 = getenv("X3S_NS") && atoi(getenv("X3S_NS")) == 1;
+            switch (mt) {
+                case 1: if (ns1) hipLaunchKernelGGL((gemm_nt_x3s_kernel<1, 1>), g, dim3(X3S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_x3s_kernel<1, 2>), g, dim3(X3S_THREADS), 0, st, a); break;
+                case 2: if (ns1) hipLaunchKernelGGL((gemm_nt_x3s_kernel<2, 1>), g, dim3(X3S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_x3s_kernel<2, 2>), g, dim3(X3S_THREADS), 0, st, a); break;
+                case 3: if (ns1) hipLaunchKernelGGL((gemm_nt_x3s_kernel<3, 1>), g, dim3(X3S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_x3s_kernel<3, 2>), g, dim3(X3S_THREADS), 0, st, a); break;
+                case 4: if (ns1) hipLaunchKernelGGL((gemm_nt_x3s_kernel<4, 1>), g, dim3(X3S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_x3s_kernel<4, 2>), g, dim3(X3S_THREADS), 0, st, a); break;
+                case 5: if (ns1) hipLaunchKernelGGL((gemm_nt_x3s_kernel<5, 1>), g, dim3(X3S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_x3s_kernel<5, 2>), g, dim3(X3S_THREADS), 0, st, a); break;
+                case 6: if (ns1) hipLaunchKernelGGL((gemm_nt_x3s_kernel<6, 1>), g, dim3(X3S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_x3s_kernel<6, 2>), g, dim3(X3S_THREADS), 0, st, a); break;
+                case 7: if (ns1) hipLaunchKernelGGL((gemm_nt_x3s_kernel<7, 1>), g, dim3(X3S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_x3s_kernel<7, 2>), g, dim3(X3S_THREADS), 0, st, a); break;
+                default: if (ns1) hipLaunchKernelGGL((gemm_nt_x3s_kernel<8, 1>), g, dim3(X3S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_x3s_kernel<8, 2>), g, dim3(X3S_THREADS), 0, st, a); break;
+            }
+        }
+        else if (is_x3(tm) && tn == 21) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), g, dim3(X3_THREADS), 0, st, a);
         else if (is_x3(tm)) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), g, dim3(X3_THREADS), 0, st, a);
         else if (tm == 1664 && tn == 21) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 1>), g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 1665 && tn == 21) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<true, 1>), g, dim3(B16_THREADS), 0, st, a);
@@ -277,8 +300,8 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
     auto rnd = [&](int lo, int hi) { st = st * 1664525u + 1013904223u; return lo + (int)((st >> 8) % (unsigned)(hi - lo + 1)); };
     int bad = 0;
     for (int cs = 0; cs < cases; ++cs) {
-        const int slots = (int[]){8, 64, 256, 256}[rnd(0, 3)];
-        const int aligned = rnd(0, 1);
+        const int slots = tm == 3400 ? (int[]){64, 256, 384, 768}[rnd(0, 3)] : (int[]){8, 64, 256, 256}[rnd(0, 3)];
+        const int aligned = tm == 3400 ? 1 : rnd(0, 1);      // (the weight-streaming kernel only has k-aligned pieces)
         if (aligned) setenv("GEMM_PLAN_ALIGNED", rnd(0, 1) ? "8" : "2", 1); else unsetenv("GEMM_PLAN_ALIGNED");
         Builder b(slots, rnd(1, 8), tm, tn);
         const int nprob = rnd(1, 3);
@@ -287,7 +310,7 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
         std::vector<void*> to_free;
         for (int p = 0; p < nprob; ++p) {
             Host& h = H[p];
-            h.M = rnd(0, 5) == 0 ? rnd(1, 20) : rnd(1, 600);
+            h.M = rnd(0, 5) == 0 ? rnd(1, 20) : rnd(1, tm == 3400 ? 128 : 600);
             h.N = rnd(0, 5) == 0 ? rnd(1, 40) : rnd(8, 700);
             h.coff = rnd(0, 1) ? 4 * rnd(0, 3) : rnd(0, 5);
             h.ldc = h.N + h.coff + (rnd(0, 1) ? 4 * rnd(0, 4) : rnd(0, 7));

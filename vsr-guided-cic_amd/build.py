@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "vsrcap.hip")
-GEMM_HEADERS = [os.path.join(HERE, "csrc", f) for f in ("gemm_f32.h", "gemm_bf16.h", "gemm_x3.h")]
+GEMM_HEADERS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.startswith("gemm_"))
 DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith((".h", ".hip"))) + \
        [os.path.join(os.path.dirname(HERE), "include", "vsrcap.h")]
 OUT = os.path.join(HERE, "vsrcap", "libvsrcap.so")

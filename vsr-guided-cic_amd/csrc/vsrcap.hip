@@ -27,6 +27,7 @@
 #include "gemm_f32.h"
 #include "gemm_bf16.h"
 #include "gemm_x3.h"
+#include "gemm_x3s.h"
 #include "kernels.h"
 #include "train_kernels.h"
 
@@ -125,6 +126,11 @@ struct vsr_handle {
     // (its wide launches have 2000 rows) 9.52 k against 9.40 k samples/s; greedy (M = 100) 572 k with aligned pieces against 550 k
     int x3_aligned_wide = 2, x3_aligned_skinny = 1;
     int x3_aligned_min = 4;      // shortest k-aligned piece of the f32x3 kernels, in 32-wide k-tiles
+    // f32x3 launches of at most x3s_max rows: the weight-streaming kernel (gemm_x3s.h) when its k-aligned plan exists.  Measured over
+    // the four step GEMMs (tools/gemm_bench, one 16-column strip per wave, two workgroups per CU): M = 13: 53 us against 65 (rows-16
+    // kernel); M = 32: 61 against 76; M = 65: 99 against 107 (128 x 128 tile); M = 100: 123 against 112 - so up to 80 rows.
+    // VSR_X3S_MAX=0 turns it off.
+    int x3s_max = 80, x3s_slots = 512, x3s_min = 8;
     int gemm_slots_r16 = 256;    // rows-16 kernel: ONE 8-wave workgroup per CU (two waves per SIMD)
     // Problems with at most this many rows take the rows-16 kernel (VSR_GEMM_R16_MAX=0 disables it).  Measured end to end on
     // one MI355X: at M = 100 it is level with the 64x64 kernel inside a GEMM (61.5 vs 60.6 TF/s) but its tiles are cut into
@@ -248,6 +254,7 @@ struct GemmBuilder {
     int big = 0;       // 2: 128x128 workgroup tiles, 1: 128x64, 0: 64x64 (32x32x2 MFMA); 16: rows-16 kernel (16x16x4 MFMA), r16_tm tiles
     int r16_tm = 0;
     int x3_tn = 2;       // f32x3 and bf16 kernels: workgroup tile 128 x 256 (2) or 128 x 128 (1)
+    int x3s_mt = 0;      // weight-streaming f32x3 kernel (big = 34): 16-row tiles of A
     bool a16_all = false;   // bf16 kernel: every segment's A operand has a bf16 image (GemmSeg::A16)
     bool stale_w = false;   // bf16 mode: a W operand exists only as a bf16 image but the launch does not qualify for the bf16 kernel
     // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
@@ -304,6 +311,12 @@ struct GemmBuilder {
                          ((reinterpret_cast<uintptr_t>(S.A) & 15) == 0);
                 }
             const bool wide = ok && maxM >= h->gemm_x3_min_rows;
+            const bool stream = ok && !wide && h->x3_skinny && maxM <= h->x3s_max;
+            if (stream) {
+                // weight-streaming kernel: 64-column blocks x k-aligned pieces, two workgroups per CU
+                GemmArgs as = a;
+                if (const int ns = gemm_plan_aligned(as, h->x3s_slots, h->x3s_min, 128, x3s_bn(1), X3_BK)) { a = as; big = 34; x3s_mt = (maxM + 15) / 16; return ns; }
+            }
             const bool skinny = ok && !wide && h->x3_skinny && maxM <= 128 && maxM > h->gemm_r16_max;
             if (wide || skinny) {
                 big = 33;
@@ -359,10 +372,21 @@ struct GemmBuilder {
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     if (stale_w) return fail("bf16 mode: a GEMM launch names a transposed operand that only exists as a bf16 image but cannot take the bf16 kernel (K / leading dimensions must be multiples of 8)");
-    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : big == 33 ? X3_THREADS : big == 16 ? 512 : 256);
+    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : big == 33 ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34: 256 = X3S_THREADS)
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
-    if (big == 33 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), grid, block, 0, s, a);
+    if (big == 34) {
+        switch (x3s_mt) {
+            case 1: hipLaunchKernelGGL((gemm_nt_x3s_kernel<1, 1>), grid, block, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((gemm_nt_x3s_kernel<2, 1>), grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL((gemm_nt_x3s_kernel<3, 1>), grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL((gemm_nt_x3s_kernel<4, 1>), grid, block, 0, s, a); break;
+            case 5: hipLaunchKernelGGL((gemm_nt_x3s_kernel<5, 1>), grid, block, 0, s, a); break;
+            case 6: hipLaunchKernelGGL((gemm_nt_x3s_kernel<6, 1>), grid, block, 0, s, a); break;
+            case 7: hipLaunchKernelGGL((gemm_nt_x3s_kernel<7, 1>), grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL((gemm_nt_x3s_kernel<8, 1>), grid, block, 0, s, a); break;
+        }
+    } else if (big == 33 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 33) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), grid, block, 0, s, a);
     else if (big == 32 && a16_all && x3_tn == 1) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<true, 1>), grid, block, 0, s, a);
     else if (big == 32 && x3_tn == 1) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 1>), grid, block, 0, s, a);
@@ -418,9 +442,13 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
         h->gemm_slots_small = prop.multiProcessorCount * 3;
         h->gemm_slots_r16 = prop.multiProcessorCount;
         h->gemm_slots_bf16 = prop.multiProcessorCount;
+        h->x3s_slots = prop.multiProcessorCount * 2;
     }
     if (const char* e = getenv("VSR_X3_MIN_ROWS")) h->gemm_x3_min_rows = atoi(e);
     if (const char* e = getenv("VSR_X3_SKINNY")) h->x3_skinny = atoi(e);
+    if (const char* e = getenv("VSR_X3S_MAX")) h->x3s_max = atoi(e);
+    if (const char* e = getenv("VSR_X3S_SLOTS")) h->x3s_slots = std::max(1, atoi(e));
+    if (const char* e = getenv("VSR_X3S_MIN")) h->x3s_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_X3_ALIGNED")) { h->x3_aligned_wide = atoi(e) / 10; h->x3_aligned_skinny = atoi(e) % 10; }
     if (const char* e = getenv("VSR_X3_ALIGNED_MIN")) h->x3_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_BF16")) h->gemm_slots_bf16 = std::max(1, atoi(e));
