@@ -1,17 +1,22 @@
 #!/bin/bash
-# f32x3 kernel variants: fuzz + timings on the decoder shapes (M = 500 and M = 100), stream-K and k-aligned plans
+# f32x3 kernel variants on the decoder's step shapes: fuzz + timings, stream-K ranges and k-aligned pieces.  usage: tools/x3_round.sh <tag>
 OUT=gpurun_out/${1:-x3}; mkdir -p $OUT
-for v in "3300 1" "3301 22" "3311 22" "3301 21" "3311 21" "3301 11" "3311 11"; do
+for v in "3300 1" "3300 21" "3400 1" "1664 21" "1665 21"; do
   timeout 300 tools/gemm_bench fuzz $v 12 7 2>&1 | tail -1 | sed "s/^/fuzz $v: /"
 done 2>&1 | tee $OUT/fuzz.txt
-for M in 500 100; do
-  for v in "1 1" "3300 1" "3301 22" "3311 22" "3311 21" "3311 11" "3301 11"; do
-    for al in 0 8; do
-      [ "$v" = "1 1" ] && [ $al = 8 ] && continue
-      slots=256; [ "$v" = "1 1" ] && slots=768
-      if [ $al = 0 ]; then r=$(timeout 120 tools/gemm_bench $M $slots 4 $v 2>&1 | grep -E "^S[0-9]|^step|correctness" | tr '\n' '|');
-      else r=$(GEMM_PLAN_ALIGNED=$al timeout 120 tools/gemm_bench $M $slots 4 $v 2>&1 | grep -E "^S[0-9]|^step|correctness" | tr '\n' '|'); fi
-      echo "M=$M v=$v aligned=$al: $r"
-    done
+run() {   # M variant tn aligned slots
+  if [ $4 = 0 ]; then r=$(timeout 120 tools/gemm_bench $1 $5 4 $2 $3 2>&1 | grep -E "^S[0-9]|^step" | tr '\n' '|');
+  else r=$(GEMM_PLAN_ALIGNED=$4 timeout 120 tools/gemm_bench $1 $5 4 $2 $3 2>&1 | grep -E "^S[0-9]|^step" | tr '\n' '|'); fi
+  echo "M=$1 v=$2 $3 aligned=$4 slots=$5: $r" | sed "s/nslab //g; s/ TF\/s//g"
+}
+{
+  for al in 0 4; do run 500 3300 1 $al 256; run 500 3300 21 $al 256; done
+  run 500 1 1 0 768
+  for M in 100 65 32 13; do
+    run $M 3300 21 4 256
+    X3S_NS=1 run $M 3400 1 8 512
+    X3S_NS=2 run $M 3400 1 8 256
+    run $M 1 1 0 768
+    run $M 160$(( (M > 112 ? 112 : M + 15) / 16 )) 2 0 256
   done
-done 2>&1 | tee $OUT/timing.txt
+} 2>&1 | tee $OUT/timing.txt
