@@ -1035,42 +1035,43 @@ __global__ __launch_bounds__(64) void k_select_beam(int t, int cb, int beam, int
                                                     int* __restrict__ hist_gate, float* __restrict__ hist_lpw,
                                                     float* __restrict__ hist_lpg, int B) {
     const int b = blockIdx.x, lane = threadIdx.x;
-    __shared__ float mw_s[KMAX], mg_s[KMAX];
-    // stream masks of the CURRENT beams (updated with the outputs selected at t-1)
-    if (lane < cb) {
-        float mw = 1.f, mg = 1.f;
-        if (t > 0) {
-            mw = mask_in[(b * beam + lane) * 2] * ((word_prev[b * cb + lane] != eos_w) ? 1.f : 0.f);
-            mg = mask_in[(b * beam + lane) * 2 + 1] * ((gate_prev[b * cb + lane] != eos_g) ? 1.f : 0.f);
-        }
-        mw_s[lane] = mw;
-        mg_s[lane] = mg;
-    }
-    __syncthreads();
     const int ncand = cb * K * 2;
-    // each lane owns up to 2 candidates (ncand <= 128)
-    float cv[2];
-    int cj[2], cw[2], cg[2];
+    // each lane owns up to 2 candidates (ncand <= 128) and loads everything a winner will have to write with them: the selection
+    // rounds below are shuffles only (a winner that went back to memory for its log-probs paid up to K dependent round trips)
+    float cv[2], cmw[2], cmg[2], clw[2], clg[2];
+    int cj[2], cw[2], cg[2], ck[2];
     long long cflat[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int c = lane + 64 * u;
-        cv[u] = -INFINITY; cj[u] = 0; cw[u] = 0; cg[u] = 0; cflat[u] = 0x7fffffffffffffffLL;
+        cv[u] = -INFINITY; cj[u] = 0; cw[u] = 0; cg[u] = 0; ck[u] = 0; cflat[u] = 0x7fffffffffffffffLL;
+        cmw[u] = 1.f; cmg[u] = 1.f; clw[u] = 0.f; clg[u] = 0.f;
         if (c < ncand) {
             const int j = c / (2 * K), i = (c / 2) % K, g = c & 1;
             const int row = b * cb + j;
+            // stream masks of the CURRENT beams (updated with the outputs selected at t-1)
+            float mw = 1.f, mg = 1.f;
+            if (t > 0) {
+                mw = mask_in[(b * beam + j) * 2] * ((word_prev[row] != eos_w) ? 1.f : 0.f);
+                mg = mask_in[(b * beam + j) * 2 + 1] * ((gate_prev[row] != eos_g) ? 1.f : 0.f);
+            }
             const float seq = (t > 0) ? seq_in[b * beam + j] : 0.f;
-            const float alive = fminf(fmaxf(mw_s[j] + mg_s[j], 0.f), 1.f);
+            const float alive = fminf(fmaxf(mw + mg, 0.f), 1.f);
+            const int wi = top_i[(long long)row * K + i];
+            const float lw = top_v[(long long)row * K + i], lgv = lg[row * 2 + g];
             int w;
             float val;
             if (alive != 0.f) {
-                w = top_i[(long long)row * K + i];
-                val = seq + (top_v[(long long)row * K + i] + lg[row * 2 + g]);
-            } else {            // frozen hypothesis: word 0 keeps the old score, everything else -999
+                w = wi;
+                val = seq + (lw + lgv);
+                clw[u] = lw;              // (ids are distinct within a row's list: the selection's word log-prob is this entry's)
+            } else {            // frozen hypothesis: word 0 keeps the old score, everything else -999; its word log-prob reads 0
                 w = i;
                 val = (i == 0) ? seq : -999.f;
             }
-            cv[u] = val; cj[u] = j; cw[u] = w; cg[u] = g;
+            const int k = slot[row] + g;
+            ck[u] = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);
+            cv[u] = val; cj[u] = j; cw[u] = w; cg[u] = g; cmw[u] = mw; cmg[u] = mg; clg[u] = lgv;
             cflat[u] = ((long long)j * 0x40000000LL + w) * 2 + g;
         }
     }
@@ -1096,25 +1097,16 @@ __global__ __launch_bounds__(64) void k_select_beam(int t, int cb, int beam, int
             word_next[orow] = w;
             gate_next[orow] = g;
             parent_row[orow] = prow;
-            int k = slot[prow] + g;
-            slot_next[orow] = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);
-            mask_out[orow * 2] = mw_s[j];
-            mask_out[orow * 2 + 1] = mg_s[j];
+            slot_next[orow] = ck[u];
+            mask_out[orow * 2] = cmw[u];
+            mask_out[orow * 2 + 1] = cmg[u];
             const long long hrow = (long long)t * B * beam + orow;
             hist_parent[hrow] = j;
             hist_word[hrow] = w;
             hist_gate[hrow] = g;
             // returned per-slot log-probs: log-prob of the selection, zeroed once its stream saw EOS
-            float lw = 0.f;
-            {   // find the word's log-prob among the parent's top-K list (frozen rows: not in the list -> use 0 * mask)
-                const float alive = fminf(fmaxf(mw_s[j] + mg_s[j], 0.f), 1.f);
-                if (alive != 0.f) {
-                    for (int i = 0; i < K; ++i)
-                        if (top_i[(long long)prow * K + i] == w) { lw = top_v[(long long)prow * K + i]; break; }
-                }
-            }
-            hist_lpw[hrow] = lw * mw_s[j];
-            hist_lpg[hrow] = lg[prow * 2 + g] * mg_s[j];
+            hist_lpw[hrow] = clw[u] * cmw[u];
+            hist_lpg[hrow] = clg[u] * cmg[u];
             cv[u] = -INFINITY;
             cflat[u] = 0x7fffffffffffffffLL;
         }
