@@ -323,18 +323,21 @@ void gemm_nt_x3_kernel(const GemmArgs args) {
                     bm[j] = *reinterpret_cast<const bf16x8_t*>(b_row + PLANE + j * 32 * X3_ROW + ch);
                     bl[j] = *reinterpret_cast<const bf16x8_t*>(b_row + 2 * PLANE + j * 32 * X3_ROW + ch);
                 }
-                // smallest terms first, the leading product last
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
+                // smallest terms first, the leading product last; term-major over the TM x TN accumulators (consecutive MFMAs of one
+                // accumulator are TM x TN issues apart; written accumulator-major hipcc alternates two accumulators: 1-3 % slower on
+                // the 128 x 256 tile.  Issuing each product's LDS reads one product ahead by hand - a software pipeline with four live
+                // plane operands, sched_barrier between the stages - measured no better: the SIMD's other multiplier wave hides them)
+#define X3_TERM(X, Y)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[i], Y[j], acc[i][j], 0, 0, 0);
+                X3_TERM(al, bh)
+                X3_TERM(ah, bl)
+                X3_TERM(am, bm)
+                X3_TERM(am, bh)
+                X3_TERM(ah, bm)
+                X3_TERM(ah, bh)
+#undef X3_TERM
             }
             if (end_of_ktile(std::true_type{})) zero_acc();
         }
