@@ -6,7 +6,6 @@ tools/gemm_bench_abl_<name>.  The patched kernels compute garbage - only their l
   nomfma    multipliers read their operands from LDS but issue no MFMA
   nolds     multipliers issue their MFMAs on registers they never load (no LDS reads)
   nomove    movers neither load, split nor store: barriers only
-  noload    movers split and store whatever their registers hold: no global loads, no waits
   nostore   movers load and split, the planes are not written to LDS
 usage: tools/x3_ablate.py [names...]   (default: all)"""
 import os, shutil, subprocess, sys
@@ -32,7 +31,6 @@ PATCHES = {
                ("            for (int i = 0; i < LA; ++i) put(buf, lrow + 64 * i, ra[s][i], stl[s]);\n", "            for (int i = 0; i < 0; ++i) put(buf, lrow + 64 * i, ra[s][i], stl[s]);\n"),
                ("            for (int i = 0; i < LB; ++i) put(buf, BM + lrow + 64 * i, rb[s][i], stl[s]);\n", "            for (int i = 0; i < 0; ++i) put(buf, BM + lrow + 64 * i, rb[s][i], stl[s]);\n")],
 }
-PATCHES["noload"] = PATCHES["nomove"][:5]
 PATCHES["nostore"] = [("            *reinterpret_cast<uint2*>(buf + pos) = make_uint2(h0, h1);\n"
                        "            *reinterpret_cast<uint2*>(buf + PLANE + pos) = make_uint2(m0, m1);\n"
                        "            *reinterpret_cast<uint2*>(buf + 2 * PLANE + pos) = make_uint2(l0, l1);\n",
