@@ -492,33 +492,43 @@ def main():
             line["cpu_baseline"] = cpu_baseline_xe(weights, min(args.cpu_sample, 16), torch, synth)
     else:
         line, weights, beam = decode_bench(args, D, torch, dist, synth)
+        def optional(what, fn):
+            # the legs below ride along with the headline: a failure in one of them (the same code on every rank, so a Python-level
+            # error is raised by all ranks together) is reported in its place instead of costing the run its headline value
+            try:
+                return fn()
+            except Exception as e:                              # noqa: BLE001 - reported, not swallowed
+                print("bench.py: optional leg %s failed: %r" % (what, e), file=sys.stderr)
+                return {"error": "%s: %r" % (what, e)}
+
+        def xe_leg(dt, full):
+            xb = argparse.Namespace(**vars(args))
+            xb.workload, xb.dtype = "xe", dt
+            bl, _ = train_bench(xb, D, torch, dist, synth, max(5, args.steps // 2), 2)
+            keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "config", "roofline") if full \
+                else ("value", "unit", "ms_per_step", "steps", "dtype", "roofline")
+            return {k: bl[k] for k in keys}
+
+        def decode_leg(dt):
+            aa = argparse.Namespace(**vars(args))
+            aa.dtype = dt
+            aa.steps, aa.warmup = max(5, args.steps // 2), 2
+            al, _, _ = decode_bench(aa, D, torch, dist, synth)
+            return {k: al[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline")}
+
         if args.workload == "beam5" and not args.no_secondary:
             # the other half of BASELINE.json's metric in the same driver-timed run
-            xa = argparse.Namespace(**vars(args))
-            xa.workload = "xe"
-            xe_line, _ = train_bench(xa, D, torch, dist, synth, max(5, args.steps // 2), 2)
-            line["secondary"] = {k: xe_line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
-                                                         "scaling", "dtype", "config", "roofline")}
-            if not args.no_alt:
+            line["secondary"] = optional("secondary XE step", lambda: xe_leg(args.dtype, True))
+            if not args.no_alt and "error" not in line["secondary"]:
                 # configs[3] names bf16: the same XE step in the throughput mode, and in the exact-chain flavour, side by side
-                line["secondary"]["alt_modes"] = {}
-                for dt in [d for d in ("f32", "bf16") if d != args.dtype]:
-                    xb = argparse.Namespace(**vars(xa))
-                    xb.dtype = dt
-                    bl, _ = train_bench(xb, D, torch, dist, synth, max(5, args.steps // 2), 2)
-                    line["secondary"]["alt_modes"][dt] = {k: bl[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline")}
+                line["secondary"]["alt_modes"] = {dt: optional("XE step " + dt, lambda dt=dt: xe_leg(dt, False))
+                                                  for dt in ("f32", "bf16") if dt != args.dtype}
         if args.workload == "beam5" and not args.no_alt:
             # the same workload in the other GEMM flavours, always printed side by side (never the headline `value`):
             #   f32   = the exact k-ordered fp32 fma chain for every launch (v_mfma_f32_32x32x2_f32)
             #   f32x3 = fp32 products from three bf16 terms per operand (same fixtures, same bounds: the GPU suite runs in both)
             #   bf16  = throughput mode (tests/test_gpu_bf16.py states its deviation)
-            line["alt_modes"] = {}
-            for dt in [d for d in ("f32", "f32x3", "bf16") if d != args.dtype]:
-                aa = argparse.Namespace(**vars(args))
-                aa.dtype = dt
-                aa.steps, aa.warmup = max(5, args.steps // 2), 2
-                al, _, _ = decode_bench(aa, D, torch, dist, synth)
-                line["alt_modes"][dt] = {k: al[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "roofline")}
+            line["alt_modes"] = {dt: optional("beam-5 " + dt, lambda dt=dt: decode_leg(dt)) for dt in ("f32", "f32x3", "bf16") if dt != args.dtype}
         if D.rank == 0 and D.world == 1 and not args.no_cpu and args.workload != "beam5idx":
             line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam, torch, synth, full_B=CFG["B"] if args.cpu_full else 0)
     if D.rank == 0:
