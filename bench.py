@@ -2,7 +2,7 @@
 """bench.py - headline benchmark of the VSR captioning decoder hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload beam5|beam5idx|greedy|xe|xeidx|scst]
-                    [--scaling weak|strong] [--dtype f32x3|f32|bf16] [--no-cpu] [--no-secondary] [--no-alt]
+                    [--scaling weak|strong] [--dtype f16x2|f32x3|f32|bf16] [--no-cpu] [--no-secondary] [--no-alt]
 
 Headline (BASELINE.json metric, configs[2]): beam-5 decode through ControllableCaptioningModel.beam_search, batch 100
 images per GPU, 36 regions x 2048-d, 10 slots, seq_len 20, vocab 10 000, fp32 operands and accumulation (the reference's
@@ -254,13 +254,26 @@ def roofline_block(dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic=No
                 "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1), "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt,
                 "mfma_tflops_for_reference": achieved, "mfma_frac_of_dense_bf16_peak": achieved / PEAK_BF16_MFMA_TFLOPS}
     peak = PEAK_F32_MFMA_TFLOPS
-    if dtype == "f32x3":
-        r = {"bound": "mfma", "kernel": "gemm_nt_f32x3_kernel (fp32 operands split into 3 bf16 terms, 6 x v_mfma_f32_32x32x16_bf16 per product; "
-                                         "launches of <= 192 rows: the exact fp32 kernels of gemm_f32.h)",
-             "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS / 6.0, "unit": "TFLOP/s (fp32-equivalent)", "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / 6.0),
+    if dtype in ("f32x3", "f16x2"):
+        # fp32-equivalent peak = the dense bf16 / fp16 MFMA peak over the MFMAs one fp32 product costs (six / three)
+        nmfma = 6.0 if dtype == "f32x3" else 3.0
+        kernel = ("gemm_nt_x3_kernel<2,2> / <2,1> (128 x 256 / 128 x 128 tiles; from 193 / up to 128 rows) and gemm_nt_x3s_kernel (weight streaming, "
+                  "<= 80 rows): fp32 operands split into 3 bf16 terms in the kernel, 6 x v_mfma_f32_*_bf16 per product; launches of 129-192 rows: "
+                  "the exact fp32 kernels of gemm_f32.h") if dtype == "f32x3" else \
+                 ("gemm_nt_h2_kernel<2,2> / <2,1> (128 x 256 / 128 x 128 tiles, > 128 rows) and gemm_nt_h2s_kernel (weight streaming, <= 128 rows): "
+                  "fp32 operands as 2 fp16 terms under a power-of-two scale, 3 x v_mfma_f32_*_f16 per product, weights pre-split into fp16-pair "
+                  "images (4 B / element) per weight version, A split in the kernel; the backward pass of training runs the f32x3 kernels")
+        r = {"bound": "mfma", "kernel": kernel,
+             "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS / nmfma, "unit": "TFLOP/s (fp32-equivalent)", "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / nmfma),
              "traffic": traffic, "launches": gemm_seen, "launches_timed": gemm_n, "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1),
              "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt, "algorithmic_flops_per_launch": gemm_flops / max(gemm_n, 1),
              "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+        if dtype == "f16x2":
+            # at three MFMAs per product the launches are paced by the bytes a CU takes in, not by the matrix pipe: the same launches
+            # against the HBM roofline (algorithmic bytes: every operand and output element once)
+            gbs = gemm_bytes / (gemm_ms * 1e-3) / 1e9 if gemm_ms > 0 else 0.0
+            r["hbm_view"] = {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                             "algorithmic_bytes_per_launch": gemm_bytes / max(gemm_n, 1)}
         if traffic_source:
             r["traffic_source"] = traffic_source + " (quoted from the committed rocprofv3 PMC passes of this command, not re-measured in this run)"
         return r
@@ -330,7 +343,7 @@ def decode_bench(args, D, torch, dist, synth):
     name = "beam-5" if beam > 1 else "greedy"
     traffic, tsrc = (None, None)
     if beam > 1 and not indexed:                                        # the workloads the committed PMC passes were taken on
-        traffic, tsrc = traffic_from_profiles({"f32": "gemm", "bf16": "gemm_bf16", "f32x3": "gemm_f32x3"}[args.dtype])
+        traffic, tsrc = traffic_from_profiles({"f32": "gemm", "bf16": "gemm_bf16", "f32x3": "gemm_f32x3", "f16x2": "gemm_f16x2"}[args.dtype])
     line = {
         "metric": ("decoded tokens/sec at batch=100, beam=5, 36x2048 regions" + (", index-list region format" if indexed else ""))
                   if beam > 1 else "decoded tokens/sec, greedy, batch=100, 36x2048 regions",
@@ -460,13 +473,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="beam5", choices=["beam5", "beam5idx", "greedy", "xe", "xeidx", "scst"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--dtype", default="f32x3", choices=["f32", "f32x3", "bf16"],
-                    help="f32x3 = parity mode (headline): fp32 operands, fp32 accumulation, products of launches > 192 rows from three bf16 "
-                         "terms per operand; f32 = the exact fp32 fma chain for every launch; bf16 = throughput mode (bf16 operands, "
-                         "fp32 accumulate, fp32 master weights)")
+    ap.add_argument("--dtype", default="f16x2", choices=["f32", "f32x3", "f16x2", "bf16"],
+                    help="f16x2 = parity mode (headline): fp32 operands in memory, fp32 accumulation, every product from two fp16 terms per operand "
+                         "under a power-of-two scale (3 MFMAs), weights pre-split per weight version (csrc/gemm_h2.h); f32x3 = the same with three "
+                         "bf16 terms (6 MFMAs, csrc/gemm_x3.h; launches of 129-192 rows on the exact kernels); f32 = the exact fp32 fma chain for "
+                         "every launch; bf16 = throughput mode (bf16 operands, fp32 accumulate, fp32 master weights).  Every parity test runs in "
+                         "f16x2, f32x3 and f32 (tests/conftest.py)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the XE-step leg of the default line")
-    ap.add_argument("--no-alt", action="store_true", help="skip the f32x3 / bf16 legs of the default line")
+    ap.add_argument("--no-alt", action="store_true", help="skip the other-flavour legs (f32 / f32x3 / f16x2 / bf16) and the greedy / 13-image legs of the default line")
     ap.add_argument("--cpu-sample", type=int, default=12)
     ap.add_argument("--cpu-full", type=int, default=1, help="1: the CPU baseline's value is ONE as-written call at the workload's own batch size (0: the bounded sample only)")
     ap.add_argument("--batch", type=int, default=0, help="images per batch instead of 100 (experiments only: not the BASELINE workload)")
@@ -526,9 +541,26 @@ def main():
         if args.workload == "beam5" and not args.no_alt:
             # the same workload in the other GEMM flavours, always printed side by side (never the headline `value`):
             #   f32   = the exact k-ordered fp32 fma chain for every launch (v_mfma_f32_32x32x2_f32)
-            #   f32x3 = fp32 products from three bf16 terms per operand (same fixtures, same bounds: the GPU suite runs in both)
+            #   f32x3 = fp32 products from three bf16 terms per operand, f16x2 = from two fp16 terms (same fixtures, same bounds: the GPU
+            #           suite runs in every one of them)
             #   bf16  = throughput mode (tests/test_gpu_bf16.py states its deviation)
-            line["alt_modes"] = {dt: optional("beam-5 " + dt, lambda dt=dt: decode_leg(dt)) for dt in ("f32", "f32x3", "bf16") if dt != args.dtype}
+            line["alt_modes"] = {dt: optional("beam-5 " + dt, lambda dt=dt: decode_leg(dt)) for dt in ("f32", "f32x3", "f16x2", "bf16") if dt != args.dtype}
+            # the regimes the one-m-tile kernels serve, driver-timed: greedy decoding (configs[1], M = 100) and the 13-image shard of a
+            # strong-scaled batch (M = 13 / 65): short legs in the headline's flavour, never the headline `value`
+            def workload_leg(workload, batch):
+                aa = argparse.Namespace(**vars(args))
+                aa.workload = workload
+                aa.steps, aa.warmup = max(10, args.steps), 3
+                old_b = CFG["B"]
+                CFG["B"] = batch
+                try:
+                    al, _, _ = decode_bench(aa, D, torch, dist, synth)
+                finally:
+                    CFG["B"] = old_b
+                return {k: al[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype")} | {"batch": batch, "gemm_avg_launch_us": al["roofline"]["avg_launch_us"]}
+            if args.batch == 0 and D.world == 1:
+                line["alt_workloads"] = {"greedy": optional("greedy leg", lambda: workload_leg("greedy", CFG["B"])),
+                                         "beam5_batch13": optional("13-image leg", lambda: workload_leg("beam5", 13))}
         if D.rank == 0 and D.world == 1 and not args.no_cpu and args.workload != "beam5idx":
             line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam, torch, synth, full_B=CFG["B"] if args.cpu_full else 0)
     if D.rank == 0:

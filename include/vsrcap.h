@@ -110,12 +110,28 @@ int vsr_build_decode_cache(vsr_handle* h, float* buffer, size_t n_floats, void* 
 size_t vsr_bf16_weight_bytes(const vsr_handle* h);
 int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream);
 
-/* fp32 GEMM flavour of a handle.  1 ("f32x3", the default since round 3): in launches of more than 192 rows every fp32 operand
- * is split into three bf16 terms on its way into LDS (x = hi + mid + lo exactly) and a product is six v_mfma_f32_32x32x16_bf16
- * with fp32 accumulation; the dropped cross terms are below one fp32 rounding of the product.  Operands stay fp32 in memory
- * (no copies); shorter launches use the exact chain.  0: exact k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32 for every
- * launch.  The two are not bit-identical (a different summation order); every parity test runs in both (tests/conftest.py). */
+/* fp32 GEMM flavour of a handle.  0: exact k-ordered fp32 fma chain on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 for every launch.
+ * 1 ("f32x3", the library's default): every fp32 operand is split into three bf16 terms on its way into the matrix core
+ * (x = hi + mid + lo exactly) and a product is six v_mfma_f32_*_bf16 with fp32 accumulation; the dropped cross terms are below one
+ * fp32 rounding of the product.  Operands stay fp32 in memory (no copies).  Routing by the rows of a launch (csrc/vsrcap.hip,
+ * GemmBuilder::finish): at most 80 rows (VSR_X3S_MAX) the weight-streaming kernel of gemm_x3s.h; up to 128 rows the 128 x 128 tile of
+ * gemm_x3.h; 129 .. 192 rows the exact kernels of gemm_f32.h; from 193 rows (VSR_X3_MIN_ROWS) the 128 x 256 tile.  The flavours are
+ * not bit-identical (different summation orders); every parity test runs in each of them (tests/conftest.py).  A change of mode voids
+ * the decode cache, a saved training forward and the hoisted projections: call vsr_prepare*() again. */
 int vsr_set_gemm_mode(vsr_handle* h, int32_t mode);
+
+/* ---- "f16x2": the fp32 flavour with three MFMAs per product and weights that are never split in a kernel (csrc/gemm_h2.h) ------
+ * On top of mode 1.  vsr_refresh_h2_weights(h, buffer, ...) writes, into the caller's buffer (vsr_h2_weight_bytes, 256-byte aligned),
+ * an fp16-PAIR image of each of the 14 weight matrices - x 2^e = hi + lo with hi = f16(x 2^e), lo = f16(x 2^e - hi), e chosen per
+ * matrix from its max |x| so that nothing overflows, 4 bytes per element in the byte geometry of the fp32 matrix - plus the table of
+ * scale exponents; vsr_prepare*() then also measures the bounds of the region / detection operands.  From then on every launch whose
+ * W operands have images and whose A operands have a bound (all GEMMs of decoding and of the training FORWARD pass; the backward pass
+ * multiplies gradients and keeps mode 1's kernels) forms a product as lo.hi + hi.lo + hi.hi on v_mfma_f32_*_f16 with fp32
+ * accumulation, A being scaled and split inside the kernel.  Error against fp64 (tests/test_gpu_h2.py, next to the fma chain and f32x3):
+ * the accumulation's, not the split's.  Call it again after every weight update (the images are not views); buffer = NULL: back to
+ * mode 1 everywhere.  Sizes must be multiples of 8.  Turning it on or off voids what a change of mode voids. */
+size_t vsr_h2_weight_bytes(const vsr_handle* h);
+int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream);
 
 /* ---- workspace ------------------------------------------------------------------------------------ */
 /* bytes needed for B images with L slots of R regions, R0 pooled regions, decoding with up to `beam`

@@ -17,16 +17,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# ---- both fp32 GEMM flavours in ONE pytest invocation -------------------------------------------------------------------
-# Every `-m gpu` test of the decoder modules below runs twice: with the default flavour ('f32x3': launches of more than 192
-# rows form their products from three bf16 terms per fp32 operand, csrc/gemm_f32x3.h) and with 'f32' (the exact fma chain for
-# every launch).  Same fixtures, same bounds: that is what admits f32x3 as the parity-mode default.  The flavour is applied
-# through models.set_default_compute_dtype(), i.e. the compute dtype a freshly constructed model starts in; tests that pick
-# a dtype themselves (test_gpu_bf16.py, test_gpu_f32x3.py) are not doubled.  Child processes (the data-parallel workers,
-# bench.py) receive it as VSR_COMPUTE_DTYPE.
-FLAVOURS = ("f32x3", "f32")
+# ---- every fp32 GEMM flavour in ONE pytest invocation -------------------------------------------------------------------
+# Every `-m gpu` test of the decoder modules below runs three times: with the default flavour 'f16x2' (two fp16 terms per fp32
+# operand under a power-of-two scale, three MFMAs per product, fp16-pair weight images: csrc/gemm_h2.h), with 'f32x3' (three bf16
+# terms, six MFMAs: csrc/gemm_x3.h / gemm_x3s.h) and with 'f32' (the exact fma chain for every launch).  Same fixtures, same
+# bounds: that is what admits a flavour as the parity-mode default.  The flavour is applied through
+# models.set_default_compute_dtype(), i.e. the compute dtype a freshly constructed model starts in; tests that pick a dtype
+# themselves (test_gpu_bf16.py, test_gpu_f32x3.py, test_gpu_h2.py) are not multiplied.  Child processes (the data-parallel
+# workers, bench.py) receive it as VSR_COMPUTE_DTYPE.
+FLAVOURS = ("f16x2", "f32x3", "f32")
 DUAL_FLAVOUR_MODULES = ("test_gpu_parity", "test_gpu_configs", "test_gpu_train", "test_gpu_regions", "test_aa_gpu_dp",
-                        "test_gpu_headline", "test_gpu_graph", "test_gpu_skinny", "test_gpu_train_indexed")
+                        "test_gpu_headline", "test_gpu_train_indexed")
 
 
 def pytest_generate_tests(metafunc):

@@ -9,20 +9,9 @@
 #include <cstring>
 #include <vector>
 
-// -DGEMM_BENCH_ABLATE: the diagnostic COPIES of the three GEMM headers under tools/ablate/ (round-2 state, with the -D hooks
-// GEMM_ABLATE / GEMM_STAMP / GEMM_PHASES / GEMM_L1HOT / X3_EXP / B16_ABLATE / R16_* the measurements in DESIGN.md section 4 were
-// taken with).  The product headers under csrc/ have one code path each and no such hooks.
-#if defined(GEMM_BENCH_ABLATE)
-#include "ablate/gemm_f32.h"
-#include "gemm_bf16x3.h"
-#include "gemm_dma_variant.h"
-#include "ablate/gemm_f32x3.h"
-#error "the f32x3 variants 33xx of this tool are the product kernels of csrc/gemm_x3.h: build the ablation copy from the round-2 tree (git show 894f7fb:tools/gemm_bench.hip)"
-#include "ablate/gemm_bf16.h"
-#else
-#if defined(GEMM_STAMP) || defined(GEMM_PHASES) || defined(GEMM_ABLATE) || defined(X3_EXP) || defined(B16_ABLATE)
-#error "ablation / stamp hooks live in tools/ablate/: add -DGEMM_BENCH_ABLATE"
-#endif
+// The product headers under csrc/ have one code path each and no diagnostic hooks; the round-2 copies with the -D hooks (GEMM_ABLATE /
+// GEMM_STAMP / GEMM_PHASES / X3_EXP / B16_ABLATE ...) that produced the ablation numbers of DESIGN.md section 4 are in the history:
+// `git show 4789752:tools/ablate/gemm_f32.h` etc.  tools/x3_ablate.py patches scratch copies of the shipped headers instead.
 #define GEMM_ABLATE 0
 #include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
 #include "gemm_bf16x3.h"
@@ -30,21 +19,28 @@
 #include "../vsr-guided-cic_amd/csrc/gemm_bf16.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_x3.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_x3s.h"
-#endif
+#include "../vsr-guided-cic_amd/csrc/gemm_h2.h"
 
 using namespace vsr;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 // bf16 twins of the weight buffers (variant 1664 = gemm_nt_bf16w_kernel): same element layout, 2 bytes per element
-struct Twin { const float* f; size_t n; uint16_t* b; };
+struct Twin { const float* f; size_t n; uint16_t* b; uint32_t* h2; int slot; };
 static std::vector<Twin> g_twins;
 static bool g_bf16 = false, g_a16 = false;     // g_a16: variant 1665 = the bf16 kernel reading bf16 images of A (GemmSeg::A16)
+static bool g_h2 = false;                      // variants 5200 (wide) / 5300 (streaming): the f16x2 kernels of gemm_h2.h (fp16-pair images of W, scale exponents)
+static int* g_exps = nullptr;                  // device table of scale exponents, one slot per dev_rand buffer
+static unsigned* g_bounds = nullptr;
+static int g_nslot = 0;
+constexpr int MAX_SLOTS = 4096;
 // f32x3 kernel (gemm_x3.h): variant "3300 <tm><tn>" with <tm><tn> = 22 (128 x 256 tile; also "1") or 21 (128 x 128)
 static bool is_x3(int tm) { return tm == 3300; }
+static bool is_h2(int tm) { return tm == 5200 || tm == 5300; }
 static void set_variant_globals(int tm) {
     g_bf16 = tm == 1664 || tm == 1665;
     g_a16 = tm == 1665;
+    g_h2 = is_h2(tm);
 }
 
 static float* dev_rand(size_t n, unsigned seed) {
@@ -52,10 +48,48 @@ static float* dev_rand(size_t n, unsigned seed) {
     unsigned s = seed * 2654435761u + 12345u;
     for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
     float* d;
-    CK(hipMalloc(&d, n * sizeof(float)));
+    CK(hipMalloc(&d, (n + 8) * sizeof(float)));
+    CK(hipMemset(d, 0, (n + 8) * sizeof(float)));
     CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
-    g_twins.push_back(Twin{d, n, nullptr});
+    g_twins.push_back(Twin{d, n, nullptr, nullptr, -1});
     return d;
+}
+
+// f16x2: scale-exponent slot of a buffer (from its max |x| on the device; H2_LOOSE=<bits> loosens every bound by that many bits)
+static int slot_of(const float* p) {
+    if (!g_exps) { CK(hipMalloc(&g_exps, MAX_SLOTS * sizeof(int))); CK(hipMalloc(&g_bounds, MAX_SLOTS * sizeof(unsigned))); }
+    for (Twin& t : g_twins)
+        if (p >= t.f && p < t.f + t.n) {
+            if (t.slot < 0) {
+                if (g_nslot >= MAX_SLOTS) g_nslot = 0;          // (fuzz: slots are recycled together with the buffers)
+                t.slot = g_nslot++;
+                CK(hipMemset(g_bounds + t.slot, 0, sizeof(unsigned)));
+                hipLaunchKernelGGL(vsr::k_absmax, dim3(256), dim3(256), 0, 0, t.f, (long long)t.n, g_bounds + t.slot);
+                const int loose = getenv("H2_LOOSE") ? atoi(getenv("H2_LOOSE")) : 0;
+                int hidx[3] = {t.slot, -1, t.slot};
+                int* didx; CK(hipMalloc(&didx, sizeof(hidx))); CK(hipMemcpy(didx, hidx, sizeof(hidx), hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(vsr::k_h2_exps, dim3(1), dim3(64), 0, 0, g_bounds, didx, didx + 1, didx + 2, 1, g_exps);
+                CK(hipDeviceSynchronize());
+                CK(hipFree(didx));
+                if (loose) { int e; CK(hipMemcpy(&e, g_exps + t.slot, 4, hipMemcpyDeviceToHost)); e -= loose; CK(hipMemcpy(g_exps + t.slot, &e, 4, hipMemcpyHostToDevice)); }
+            }
+            return t.slot;
+        }
+    printf("no buffer for %p\n", (const void*)p); exit(1);
+}
+static const float* h2_image_of(const float* W) {
+    for (Twin& t : g_twins)
+        if (W >= t.f && W < t.f + t.n) {
+            if (!t.h2) {
+                const int slot = slot_of(t.f);
+                const size_t n8 = (t.n + 7) & ~size_t(7);
+                CK(hipMalloc(&t.h2, n8 * 4));
+                hipLaunchKernelGGL(vsr::k_f32_to_h2, dim3((unsigned)((n8 / 8 + 255) / 256)), dim3(256), 0, 0, t.f, t.h2, (long long)n8, g_exps, slot);
+                CK(hipDeviceSynchronize());
+            }
+            return reinterpret_cast<const float*>(t.h2) + (W - t.f);
+        }
+    printf("no image for %p\n", (const void*)W); exit(1);
 }
 
 static const float* twin_of(const float* W) {
@@ -77,8 +111,10 @@ struct Builder {
     Builder(int slots_, int min_iters_, int tm_ = 1, int tn_ = 1) : slots(slots_), min_iters(min_iters_), tm(tm_), tn(tn_) { memset(&a, 0, sizeof(a)); }
     GemmProb& prob(int M, int N, float* C, int ldc) { GemmProb& p = a.p[a.nprob++]; p.M = M; p.N = N; p.C = C; p.ldc = ldc; return p; }
     static void seg(GemmProb& p, const float* A, int lda, const int* idx, const float* W, int ldw, int K) {
-        GemmSeg& s = p.seg[p.nseg++]; s.A = A; s.lda = lda; s.a_idx = idx; s.W = g_bf16 ? twin_of(W) : W; s.ldw = ldw; s.K = K;
+        GemmSeg& s = p.seg[p.nseg++]; s.A = A; s.lda = lda; s.a_idx = idx; s.W = g_bf16 ? twin_of(W) : g_h2 ? h2_image_of(W) : W; s.ldw = ldw; s.K = K;
         s.A16 = g_a16 ? reinterpret_cast<const uint16_t*>(twin_of(A)) : nullptr;
+        s.exp_idx = 0;
+        if (g_h2) s.exp_idx = slot_of(W) | (slot_of(A) << 16);
     }
     int finish() {
         int bm = tm >= 12 ? 128 : 64 * tm, bn = tm >= 12 ? 128 : 64 * tn;
@@ -97,11 +133,20 @@ struct Builder {
             for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
             return ns;
         }
+        if (tm == 5200) { bm = 128; bn = tn == 21 ? 128 : 256; a.exps = g_exps; }    // f16x2 wide kernel
+        if (tm == 5300) {                                                            // f16x2 streaming kernel (<= 128 rows): "5300 <MT or 0 = by M>", H2S_NS=1|2 strips per wave
+            a.exps = g_exps;
+            const int mi = getenv("GEMM_PLAN_ALIGNED") ? atoi(getenv("GEMM_PLAN_ALIGNED")) : 8;
+            int ns = gemm_plan_aligned(a, slots, mi, 128, h2s_bn(getenv("H2S_NS") ? atoi(getenv("H2S_NS")) : 1), H2_BK);
+            if (!ns) { printf("h2s: the column blocks of this launch exceed %d slots\n", slots); exit(1); }
+            for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
+            return ns;
+        }
         if (tm > 1600 && tm <= 1608) { bm = 16 * (tm - 1600); bn = 64 * tn; }      // rows-16 kernel: tm = 1600 + TM, tn = TN
         if (tm == 1664 || tm == 1665) { bm = 128; bn = tn == 21 ? 128 : 256; }       // bf16 throughput kernel (bf16 W twins; 1665: bf16 A images too); tn 21: 128 x 128 tile
         int ns = 0;
         const bool b16 = tm == 1664 || tm == 1665;
-        if ((b16 || is_x3(tm)) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, b16 ? B16_BK : GEMM_BK);
+        if ((b16 || is_x3(tm) || tm == 5200) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, b16 ? B16_BK : GEMM_BK);
         if (!ns) ns = gemm_plan(a, slots, min_iters, bm, bn, b16 ? B16_BK : GEMM_BK);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
         return ns;
@@ -126,6 +171,16 @@ struct Builder {
                 default: if (ns1) hipLaunchKernelGGL((gemm_nt_x3s_kernel<8, 1>), g, dim3(X3S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_x3s_kernel<8, 2>), g, dim3(X3S_THREADS), 0, st, a); break;
             }
         }
+        else if (tm == 5300) {
+            int maxM = 0; for (int i = 0; i < a.nprob; ++i) maxM = a.p[i].M > maxM ? a.p[i].M : maxM;
+            const int mt = tn > 1 && tn <= 8 ? tn : (maxM + 15) / 16;
+            const bool ns2 = getenv("H2S_NS") && atoi(getenv("H2S_NS")) == 2;
+#define H2S(MT_) case MT_: if (ns2) hipLaunchKernelGGL((gemm_nt_h2s_kernel<MT_, 2>), g, dim3(H2S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_h2s_kernel<MT_, 1>), g, dim3(H2S_THREADS), 0, st, a); break;
+            switch (mt) { H2S(1) H2S(2) H2S(3) H2S(4) H2S(5) H2S(6) H2S(7) default: if (ns2) hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 2>), g, dim3(H2S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 1>), g, dim3(H2S_THREADS), 0, st, a); break; }
+#undef H2S
+        }
+        else if (tm == 5200 && tn == 21) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 1>), g, dim3(H2_THREADS), 0, st, a);
+        else if (tm == 5200) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2>), g, dim3(H2_THREADS), 0, st, a);
         else if (is_x3(tm) && tn == 21) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), g, dim3(X3_THREADS), 0, st, a);
         else if (is_x3(tm)) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), g, dim3(X3_THREADS), 0, st, a);
         else if (tm == 1664 && tn == 21) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 1>), g, dim3(B16_THREADS), 0, st, a);
@@ -150,11 +205,6 @@ struct Builder {
 };
 
 static double time_it(Builder& b, int reps) {
-#if defined(GEMM_STAMP)
-    static unsigned long long* dbg = nullptr;
-    if (!dbg) CK(hipMalloc(&dbg, 4096 * 32));
-    b.a.dbg = dbg;
-#endif
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) b.launch(0);
@@ -163,50 +213,6 @@ static double time_it(Builder& b, int reps) {
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-#if defined(GEMM_PHASES)
-    {
-        static unsigned long long* dbg = nullptr;
-        if (!dbg) CK(hipMalloc(&dbg, 4096 * 8 * 8));
-        CK(hipMemset(dbg, 0, 4096 * 8 * 8));
-        b.a.dbg = dbg;
-        b.launch(0);
-        CK(hipDeviceSynchronize());
-        std::vector<unsigned long long> h(8 * b.a.G);
-        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double v[5] = {0};
-        for (int i = 0; i < b.a.G; ++i) for (int q = 0; q < 5; ++q) v[q] += h[8 * i + q];
-        const double n = v[4] > 0 ? v[4] : 1;
-        printf("    per k-step (s_memtime ticks, wave 0): issue loads %.0f | multiply %.0f | wait loads + ds_write %.0f | barrier %.0f | total %.0f\n",
-               v[0] / n, v[1] / n, v[2] / n, v[3] / n, (v[0] + v[1] + v[2] + v[3]) / n);
-        b.a.dbg = nullptr;
-    }
-#endif
-#if defined(GEMM_STAMP)
-    {
-        std::vector<unsigned long long> h(4 * b.a.G);
-        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
-        double cyc = 0, ticks = 0;
-        unsigned long long s0 = ~0ull, s1 = 0, e0_ = ~0ull, e1_ = 0; double lmin = 1e30, lmax = 0;
-        int xcnt[16] = {0};
-        for (int i = 0; i < b.a.G; ++i) {
-            cyc += h[4 * i]; ticks += h[4 * i + 1];
-            unsigned long long st = h[4 * i + 2], en = st + h[4 * i + 1];
-            if (st < s0) s0 = st; if (st > s1) s1 = st; if (en < e0_) e0_ = en; if (en > e1_) e1_ = en;
-            if (h[4 * i + 1] < lmin) lmin = h[4 * i + 1]; if (h[4 * i + 1] > lmax) lmax = h[4 * i + 1];
-            xcnt[h[4 * i + 3] & 15]++;
-        }
-        printf("    clock %.0f MHz, lifetime mean %.1f min %.1f max %.1f us; starts span %.1f us, ends span %.1f us, first start->last end %.1f us; kernel %.1f us; xcc",
-               cyc / ticks * 100.0, ticks / b.a.G / 100.0, lmin / 100.0, lmax / 100.0, (s1 - s0) / 100.0, (e1_ - e0_) / 100.0, (e1_ - s0) / 100.0, ms / reps * 1e3);
-        for (int i = 0; i < 8; ++i) printf(" %d", xcnt[i]);
-        printf("\n");
-        if (getenv("GEMM_DUMP")) {
-            double xs[8] = {0}; int xn[8] = {0};
-            for (int i = 0; i < b.a.G; ++i) { xs[h[4 * i + 3] & 7] += h[4 * i + 1] / 100.0; xn[h[4 * i + 3] & 7]++; }
-            printf("    mean lifetime per XCC:"); for (int i = 0; i < 8; ++i) printf(" %.1f", xs[i] / (xn[i] ? xn[i] : 1)); printf("\n");
-            printf("    lifetime by g (every 16th):"); for (int i = 0; i < b.a.G; i += 16) printf(" %.0f", h[4 * i + 1] / 100.0); printf("\n");
-        }
-    }
-#endif
     return ms / reps;
 }
 
@@ -295,13 +301,13 @@ __global__ __launch_bounds__(512) void feed_kernel(const float* __restrict__ A, 
 // both work decompositions) of the variant under test against an fp64 host reference.  `tools/gemm_bench fuzz <tm> <tn> [cases] [seed]`
 static int fuzz(int tm, int tn, int cases, unsigned seed) {
     set_variant_globals(tm);
-    const bool wide = g_bf16 || is_x3(tm);            // the 16-wave kernels: K multiples of 8 (bf16 chunks)
+    const bool wide = g_bf16 || is_x3(tm) || is_h2(tm);            // the 16-wave kernels and the f16x2 images: K multiples of 8
     unsigned st = seed * 747796405u + 2891336453u;
     auto rnd = [&](int lo, int hi) { st = st * 1664525u + 1013904223u; return lo + (int)((st >> 8) % (unsigned)(hi - lo + 1)); };
     int bad = 0;
     for (int cs = 0; cs < cases; ++cs) {
-        const int slots = tm == 3400 ? (int[]){64, 256, 384, 768}[rnd(0, 3)] : (int[]){8, 64, 256, 256}[rnd(0, 3)];
-        const int aligned = tm == 3400 ? 1 : rnd(0, 1);      // (the weight-streaming kernel only has k-aligned pieces)
+        const int slots = (tm == 3400 || tm == 5300) ? (int[]){64, 256, 384, 768}[rnd(0, 3)] : (int[]){8, 64, 256, 256}[rnd(0, 3)];
+        const int aligned = (tm == 3400 || tm == 5300) ? 1 : rnd(0, 1);      // (the weight-streaming kernel only has k-aligned pieces)
         if (aligned) setenv("GEMM_PLAN_ALIGNED", rnd(0, 1) ? "8" : "2", 1); else unsetenv("GEMM_PLAN_ALIGNED");
         Builder b(slots, rnd(1, 8), tm, tn);
         const int nprob = rnd(1, 3);
@@ -310,7 +316,7 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
         std::vector<void*> to_free;
         for (int p = 0; p < nprob; ++p) {
             Host& h = H[p];
-            h.M = rnd(0, 5) == 0 ? rnd(1, 20) : rnd(1, tm == 3400 ? 128 : 600);
+            h.M = rnd(0, 5) == 0 ? rnd(1, 20) : rnd(1, (tm == 3400 || tm == 5300) ? 128 : 600);
             h.N = rnd(0, 5) == 0 ? rnd(1, 40) : rnd(8, 700);
             h.coff = rnd(0, 1) ? 4 * rnd(0, 3) : rnd(0, 5);
             h.ldc = h.N + h.coff + (rnd(0, 1) ? 4 * rnd(0, 4) : rnd(0, 7));
@@ -379,8 +385,9 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
         printf("fuzz %3d: %d problems (M %d N %d ...), slots %d, %s, G %d nslab %d: max |err| %.3g (tol %.3g) %s\n", cs, nprob, H[0].M, H[0].N, slots,
                b.a.aligned ? "k-aligned" : "stream-K", b.a.G, ns, worst, tol, ok ? "OK" : "FAIL");
         for (void* q : to_free) CK(hipFree(q));
-        for (Twin& t : g_twins) if (t.b) CK(hipFree(t.b));
+        for (Twin& t : g_twins) { if (t.b) CK(hipFree(t.b)); if (t.h2) CK(hipFree(t.h2)); }
         g_twins.clear();
+        g_nslot = 0;
     }
     printf("fuzz: %d of %d cases failed\n", bad, cases);
     return bad ? 1 : 0;
@@ -453,7 +460,7 @@ int main(int argc, char** argv) {
 
     // ---- correctness on a ragged problem: gather index, 3 segments with K tails, split-K, column window
     {
-        const int m = 77, n = 150, k1 = 72, k2 = 40, k3 = 100, ldw = 260, nrowsA = 200;
+        const int m = 77, n = 150, k1 = 72, k2 = 40, k3 = 100, ldw = 264, nrowsA = 200;     // (ldw a multiple of 8: the f16x2 image groups)
         float* A1 = dev_rand((size_t)nrowsA * k1, 1); float* A2 = dev_rand((size_t)nrowsA * k2, 2); float* A3 = dev_rand((size_t)m * k3, 3);
         float* W = dev_rand((size_t)n * ldw, 4);
         std::vector<int> hidx(m); for (int i = 0; i < m; ++i) hidx[i] = (i * 37 + 11) % nrowsA;

@@ -38,7 +38,7 @@ struct GemmSeg {
     int lda;
     int ldw;
     int K;               // multiple of 4
-    int pad_;
+    int exp_idx;         // f16x2 kernels only (gemm_h2.h): slots of GemmArgs::exps with the power-of-two scale exponents of W's image (low 16 bits) and of A's bound (high 16 bits)
     const uint16_t* A16; // bf16 kernel only, optional: a bf16 image of A (same rows, same lda) written by A's producer
 };
 
@@ -66,6 +66,7 @@ struct GemmArgs {
     int G;               // workgroups with a non-empty range (1 <= G <= total_iters); grid = 8 * ceil(G / 8)
     int nslab;           // slabs per tile (S)
     int aligned;         // 0: stream-K ranges (gemm_plan); 1: one k-aligned piece of one tile per workgroup (gemm_plan_aligned)
+    const int* exps;     // f16x2 kernels only: device table of scale exponents (GemmSeg::w_exp / a_exp index it)
 };
 
 // tile index -> tile origin: m fastest (the m-tiles of a weight n-tile are neighbours)

@@ -82,17 +82,44 @@ __global__ __launch_bounds__(256) void k_pool(const float* __restrict__ det, con
 }
 
 // region-row masks m[row] = (sum_d regions[row,:] != 0), one wave per row                 (step :159)
-__global__ __launch_bounds__(256) void k_rowmask(const float* __restrict__ X, long long rows, int D, float* __restrict__ mask) {
+// blockmax (optional): max |x| over the block's four rows, one float per block (the f16x2 GEMM flavour scales the region / detection
+// operands by a bound measured here, in the pass that reads them anyway; k_max_reduce folds the per-block values)
+__global__ __launch_bounds__(256) void k_rowmask(const float* __restrict__ X, long long rows, int D, float* __restrict__ mask,
+                                                 float* __restrict__ blockmax = nullptr) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    float s = 0.f;
-    for (int d = lane * 4; d < D; d += 256) {
-        float4 v = *reinterpret_cast<const float4*>(X + row * D + d);
-        s += (v.x + v.y) + (v.z + v.w);
+    float s = 0.f, mx = 0.f;
+    if (row < rows) {
+        for (int d = lane * 4; d < D; d += 256) {
+            float4 v = *reinterpret_cast<const float4*>(X + row * D + d);
+            s += (v.x + v.y) + (v.z + v.w);
+            if (blockmax) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        s = wave_sum(s);
+        if (lane == 0) mask[row] = (s != 0.f) ? 1.f : 0.f;
     }
-    s = wave_sum(s);
-    if (lane == 0) mask[row] = (s != 0.f) ? 1.f : 0.f;
+    if (blockmax) {                                       // (block-uniform)
+        __shared__ float wm[4];
+        mx = wave_max(mx);
+        if (lane == 0) wm[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) blockmax[blockIdx.x] = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    }
+}
+// *out = max(v[0 .. n)) as the bit pattern of a non-negative float (a NaN counts as +inf); one block
+__global__ __launch_bounds__(1024) void k_max_reduce(const float* __restrict__ v, long long n, unsigned* __restrict__ out) {
+    __shared__ float wm[16];
+    float m = 0.f;
+    bool nan = false;
+    for (long long i = threadIdx.x; i < n; i += 1024) { const float x = v[i]; nan |= !(x == x); m = fmaxf(m, x); }
+    if (nan) m = __int_as_float(0x7f800000);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, wm[w]);
+        *out = __float_as_uint(m);
+    }
 }
 
 // list of the non-padding region rows (ascending) and their count: att_va(0) = 0 (no bias), so the hoisted region

@@ -186,7 +186,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         const int Nn[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
         for (int i = 0; i < 3; ++i) {
             GemmProb& p = g.prob(TB, Nn[i], t.scratch + off[i], 6 * H);
-            GemmBuilder::seg(p, t.x_all, E, nullptr, Wih[i] + xoff, in1, E);
+            GemmBuilder::seg(p, t.x_all, E, nullptr, Wih[i] + xoff, in1, E, nullptr, H2A_EMBED);
         }
         const int ns = g.finish(h);
         const long long stride = (long long)TB * 6 * H;
@@ -218,8 +218,8 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
                 for (int i = 0; i < 3; ++i) {
                     if (!d.h2_first_lstm && !Whh[i]) continue;
                     GemmProb& p = g.prob(B, Nn[i], c.scratch + off[i], 6 * H);
-                    if (d.h2_first_lstm) GemmBuilder::seg(p, h2o, H, nullptr, Wih[i], in1, H);
-                    if (Whh[i]) GemmBuilder::seg(p, h1o, H, nullptr, Whh[i], H, H);
+                    if (d.h2_first_lstm) GemmBuilder::seg(p, h2o, H, nullptr, Wih[i], in1, H, nullptr, H2A_UNIT);
+                    if (Whh[i]) GemmBuilder::seg(p, h1o, H, nullptr, Whh[i], H, H, nullptr, H2A_UNIT);
                 }
                 ns = g.finish(h);
                 for (int i = 0; i < g.a.nprob; ++i) g.a.p[i].slab_stride = stride;
@@ -232,13 +232,13 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         {   // S2
             GemmBuilder g;
             GemmProb& p0 = g.prob(B, H, c.scratch, H + A);
-            GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H);
+            GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H, nullptr, H2A_UNIT);
             GemmProb& p1 = g.prob(B, A, c.scratch + H, H + A);
-            GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H);
+            GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H, nullptr, H2A_UNIT);
             GemmProb& p2 = g.prob(B, D, nullptr, D + A);
-            GemmBuilder::seg(p2, s_t, H, nullptr, w.s_fc_weight, H, H);
+            GemmBuilder::seg(p2, s_t, H, nullptr, w.s_fc_weight, H, H, nullptr, H2A_UNIT);
             GemmProb& p3 = g.prob(B, A, nullptr, D + A);
-            GemmBuilder::seg(p3, s_t, H, nullptr, w.att_sa_weight, H, H);
+            GemmBuilder::seg(p3, s_t, H, nullptr, w.att_sa_weight, H, H, nullptr, H2A_UNIT);
             const int ns = g.finish(h);
             const long long stride_a = (long long)B * (H + A), stride_b = (long long)B * (D + A);
             float* c2b = c.scratch + stride_a * ns;
@@ -260,11 +260,11 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         {   // S5
             GemmBuilder g;
             GemmProb& p0 = g.prob(B, 4 * H, c.scratch, 4 * H);
-            GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H);
-            GemmBuilder::seg(p0, att, D, nullptr, w.lstm2_weight_ih + H, in2, D);
-            if (tt > 0) GemmBuilder::seg(p0, h2o, H, nullptr, w.lstm2_weight_hh, H, H);
+            GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H, nullptr, H2A_UNIT);
+            GemmBuilder::seg(p0, att, D, nullptr, w.lstm2_weight_ih + H, in2, D, nullptr, H2A_ATT);
+            if (tt > 0) GemmBuilder::seg(p0, h2o, H, nullptr, w.lstm2_weight_hh, H, H, nullptr, H2A_UNIT);
             GemmProb& p1 = g.prob(B, A, nullptr, A);
-            GemmBuilder::seg(p1, g_t, H, nullptr, w.att_ga_weight, H, H);
+            GemmBuilder::seg(p1, g_t, H, nullptr, w.att_ga_weight, H, H, nullptr, H2A_UNIT);
             const int ns = g.finish(h);
             const long long stride = (long long)B * 4 * H, stride_g = (long long)B * A;
             float* gas = c.scratch + stride * ns;
@@ -284,7 +284,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         // (B, T, V) log-prob tensor is written row by row), then one log_softmax launch
         GemmBuilder g;
         GemmProb& p0 = g.prob(TB, V, t.scratch, V);
-        GemmBuilder::seg(p0, t.h2s, H, t.rows_bt, w.out_fc_weight, H, H);
+        GemmBuilder::seg(p0, t.h2s, H, t.rows_bt, w.out_fc_weight, H, H, nullptr, H2A_UNIT);
         const int ns = g.finish(h);
         const long long stride = (long long)TB * V;
         if ((size_t)stride * ns > t.scratch_floats) return fail("training scratch too small for the vocabulary projection (%lld x %d)", stride, ns);

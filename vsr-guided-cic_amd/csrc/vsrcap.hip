@@ -28,6 +28,7 @@
 #include "gemm_bf16.h"
 #include "gemm_x3.h"
 #include "gemm_x3s.h"
+#include "gemm_h2.h"
 #include "kernels.h"
 #include "train_kernels.h"
 
@@ -90,11 +91,29 @@ static void free_train_ctx(TrainCtx*);
 static void invalidate_train_ctx(TrainCtx*);
 
 struct Bf16Range { const float* lo; const float* hi; const uint16_t* b; };   // fp32 matrix [lo, hi) has a bf16 copy at b
+struct H2Range { const float* lo; const float* hi; const float* img; int slot; };   // ... an fp16-pair image (gemm_h2.h) at img, scale exponent in slot
+
+// f16x2 flavour: slots of the scale-exponent table (device ints at the head of the image buffer; a twin table of float bounds next to it).
+// 0..13: the 14 weight matrices; then the bounds of the A operands a GEMM segment can name (GemmBuilder::seg's a_cls)
+enum H2Slot { H2A_NONE = -1, H2A_EMBED = 14, H2A_UNIT = 15, H2A_REGION = 16, H2A_DET = 17, H2A_ATT = 18, H2B_SENT = 19, H2_NSLOT = 32 };
 
 struct vsr_handle {
     TrainCtx* tc = nullptr;
     // bf16 throughput mode (gemm_bf16.h): off unless vsr_refresh_bf16_weights() has been given a buffer
     bool bf16_on = false;
+    // f16x2 flavour (gemm_h2.h): on once vsr_refresh_h2_weights() has been given a buffer, and only together with x3_on (a launch
+    // that does not qualify - an operand without an image / a bound, sizes that are not multiples of 8 - takes the f32x3 kernels)
+    bool h2_on = false;
+    std::vector<H2Range> h2;
+    int* h2_exps = nullptr;           // device: H2_NSLOT scale exponents ...
+    unsigned* h2_bounds = nullptr;    // ... and the bounds they come from (bit patterns of non-negative floats)
+    int h2s_max = 128, h2s_slots = 512, h2s_min = 8, h2s_ns = 1;     // streaming kernel: launches of at most h2s_max rows (VSR_H2S_MAX / _SLOTS / _MIN / _NS)
+    int h2_aligned_min = 4;
+    const H2Range* map_h2(const float* p) const {
+        for (const H2Range& r : h2)
+            if (p >= r.lo && p < r.hi) return &r;
+        return nullptr;
+    }
     bool x3_on = true;                // launches of >= gemm_x3_min_rows rows: fp32 products through three bf16 terms per operand (gemm_f32x3.h); fp32 operands, no copies.  vsr_set_gemm_mode(h, 0): exact fma chain everywhere
     std::vector<Bf16Range> b16;        // weights (refresh) + the training pass's transposed operands (carve_train)
     size_t b16_weights = 0;            // entries of b16 that belong to the weights
@@ -246,10 +265,12 @@ struct GemmBuilder {
         p.M = M; p.N = N; p.C = C; p.ldc = ldc; p.nseg = 0;
         return p;
     }
-    static void seg(GemmProb& p, const float* A, int lda, const int* idx, const float* W, int ldw, int K, const uint16_t* A16 = nullptr) {
+    // a_cls: which bound the A operand obeys (H2Slot; the f16x2 kernels scale A by it); H2A_NONE: the launch cannot take them
+    static void seg(GemmProb& p, const float* A, int lda, const int* idx, const float* W, int ldw, int K, const uint16_t* A16 = nullptr, int a_cls = H2A_NONE) {
         if (K <= 0) return;
         GemmSeg& s = p.seg[p.nseg++];
         s.A = A; s.lda = lda; s.a_idx = idx; s.W = W; s.ldw = ldw; s.K = K; s.A16 = A16;
+        s.exp_idx = a_cls;               // (finish() turns it into (a slot << 16) | w slot when the launch takes the f16x2 kernels)
     }
     int big = 0;       // 2: 128x128 workgroup tiles, 1: 128x64, 0: 64x64 (32x32x2 MFMA); 16: rows-16 kernel (16x16x4 MFMA), r16_tm tiles
     int r16_tm = 0;
@@ -297,6 +318,60 @@ struct GemmBuilder {
             }
         }
         big = h->gemm_tile == 128 ? 2 : h->gemm_tile == 12864 ? 1 : h->gemm_tile == 64 ? 0 : (maxM >= 1024 ? 2 : maxM > 192 ? 1 : 0);
+        if (h->h2_on && h->x3_on && h->gemm_tile == 0) {
+            // f16x2 (gemm_h2.h): every W operand has an fp16-pair image (window starts and leading dimensions in whole 8-element
+            // groups), every A operand a bound class
+            bool ok = true;
+            for (int i = 0; i < a.nprob && ok; ++i)
+                for (int sg = 0; sg < a.p[i].nseg && ok; ++sg) {
+                    const GemmSeg& S = a.p[i].seg[sg];
+                    const H2Range* r = h->map_h2(S.W);
+                    ok = r && S.exp_idx >= 0 && (S.K % 8 == 0) && (S.ldw % 8 == 0) && (S.lda % 4 == 0) && ((S.W - r->lo) % 8 == 0) &&
+                         ((reinterpret_cast<uintptr_t>(S.A) & 15) == 0);
+                }
+            if (ok) {
+                GemmArgs ah = a;
+                for (int i = 0; i < ah.nprob; ++i)
+                    for (int sg = 0; sg < ah.p[i].nseg; ++sg) {
+                        GemmSeg& S = ah.p[i].seg[sg];
+                        const H2Range* r = h->map_h2(S.W);
+                        S.exp_idx = (S.exp_idx << 16) | r->slot;
+                        S.W = r->img + (S.W - r->lo);
+                    }
+                ah.exps = h->h2_exps;
+                const int slots = h->gemm_slots_bf16;
+                if (maxM <= h->h2s_max && maxM <= 128) {
+                    GemmArgs as = ah;
+                    if (const int ns = gemm_plan_aligned(as, h->h2s_slots, h->h2s_min, 128, h2s_bn(h->h2s_ns), H2_BK)) { a = as; big = 36; x3s_mt = (maxM + 15) / 16; return ns; }
+                }
+                big = 35;
+                a = ah;
+                auto aligned_eff = [&](GemmArgs& g) {
+                    int T = 1;
+                    for (int i = 0; i < g.nprob; ++i) T = std::max(T, (g.p[i].ktiles + g.p[i].split - 1) / g.p[i].split);
+                    return (double)g.total_iters / ((double)slots * T);
+                };
+                if (maxM <= 128) {
+                    x3_tn = 1;
+                    if (const int ns = gemm_plan_aligned(a, slots, h->h2_aligned_min, 128, 128, H2_BK)) return ns;
+                    return gemm_plan(a, slots, 4, 128, 128, H2_BK);
+                }
+                if (h->x3_aligned_wide != 0) {             // (the planner of the f32x3 wide kernel, below)
+                    const bool force = h->x3_aligned_wide == 1 || maxM >= 1024;
+                    GemmArgs a22 = a, a21 = a;
+                    const int ns22 = gemm_plan_aligned(a22, slots, h->h2_aligned_min, 128, 256, H2_BK);
+                    int tiles22 = 0;
+                    for (int i = 0; i < a.nprob; ++i) tiles22 += ((a.p[i].M + 127) / 128) * ((a.p[i].N + 255) / 256);
+                    if (tiles22 <= 64 && maxM < 1024) {
+                        const int ns21 = gemm_plan_aligned(a21, slots, h->h2_aligned_min, 128, 128, H2_BK);
+                        if (ns21 && aligned_eff(a21) >= 0.95 && (!ns22 || ns21 < ns22)) { a = a21; x3_tn = 1; return ns21; }
+                    }
+                    if (ns22 && (force || aligned_eff(a22) >= 0.75)) { a = a22; x3_tn = 2; return ns22; }
+                }
+                x3_tn = 2;
+                return gemm_plan(a, slots, 4, 128, 256, H2_BK);
+            }
+        }
         if (h->x3_on && h->gemm_tile == 0) {
             // f32x3 (gemm_x3.h): 128 x 256 tiles from 193 rows up; 128 x 128 tiles for launches whose rows fit ONE m-tile (greedy
             // decoding, sampling, the per-step GEMMs of the training pass at batch 100, a shard of a strong-scaled decode): the
@@ -372,10 +447,19 @@ struct GemmBuilder {
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     if (stale_w) return fail("bf16 mode: a GEMM launch names a transposed operand that only exists as a bf16 image but cannot take the bf16 kernel (K / leading dimensions must be multiples of 8)");
-    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : big == 33 ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34: 256 = X3S_THREADS)
+    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : (big == 33 || big == 35) ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34 / 36: 256 = X3S_THREADS = H2S_THREADS)
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
-    if (big == 34) {
+    if (big == 36) {
+#define H2S_CASE(MT_) case MT_: if (h->h2s_ns == 2) hipLaunchKernelGGL((gemm_nt_h2s_kernel<MT_, 2>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_nt_h2s_kernel<MT_, 1>), grid, block, 0, s, a); break;
+        switch (x3s_mt) {
+            H2S_CASE(1) H2S_CASE(2) H2S_CASE(3) H2S_CASE(4) H2S_CASE(5) H2S_CASE(6) H2S_CASE(7)
+            default: if (h->h2s_ns == 2) hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 2>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 1>), grid, block, 0, s, a); break;
+        }
+#undef H2S_CASE
+    } else if (big == 35 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2>), grid, block, 0, s, a);
+    else if (big == 35) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 1>), grid, block, 0, s, a);
+    else if (big == 34) {
         switch (x3s_mt) {
             case 1: hipLaunchKernelGGL((gemm_nt_x3s_kernel<1, 1>), grid, block, 0, s, a); break;
             case 2: hipLaunchKernelGGL((gemm_nt_x3s_kernel<2, 1>), grid, block, 0, s, a); break;
@@ -443,10 +527,16 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
         h->gemm_slots_r16 = prop.multiProcessorCount;
         h->gemm_slots_bf16 = prop.multiProcessorCount;
         h->x3s_slots = prop.multiProcessorCount * 2;
+        h->h2s_slots = prop.multiProcessorCount * 2;
     }
     if (const char* e = getenv("VSR_X3_MIN_ROWS")) h->gemm_x3_min_rows = atoi(e);
     if (const char* e = getenv("VSR_X3_SKINNY")) h->x3_skinny = atoi(e);
-    if (const char* e = getenv("VSR_X3S_MAX")) h->x3s_max = atoi(e);
+    if (const char* e = getenv("VSR_X3S_MAX")) h->x3s_max = std::min(atoi(e), 128);     // (the streaming kernels hold every row in ONE m-tile)
+    if (const char* e = getenv("VSR_H2S_MAX")) h->h2s_max = std::min(atoi(e), 128);
+    if (const char* e = getenv("VSR_H2S_SLOTS")) h->h2s_slots = std::max(1, atoi(e));
+    if (const char* e = getenv("VSR_H2S_MIN")) h->h2s_min = std::max(1, atoi(e));
+    if (const char* e = getenv("VSR_H2S_NS")) h->h2s_ns = atoi(e) == 2 ? 2 : 1;
+    if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_X3S_SLOTS")) h->x3s_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_X3S_MIN")) h->x3s_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_X3_ALIGNED")) { h->x3_aligned_wide = atoi(e) / 10; h->x3_aligned_skinny = atoi(e) % 10; }
@@ -527,6 +617,11 @@ extern "C" int vsr_bind_weights(vsr_handle* h, const vsr_weights* w) {
         h->b16.erase(h->b16.begin(), h->b16.begin() + h->b16_weights);
         h->b16_weights = 0;
     }
+    if (h->h2_on) {                   // ... and the fp16-pair images (vsr_refresh_h2_weights)
+        h->h2_on = false;
+        h->h2.clear();
+        h->prepared = false;
+    }
     return 0;
 }
 
@@ -555,7 +650,7 @@ extern "C" int vsr_build_decode_cache(vsr_handle* h, float* buf, size_t n_floats
         const int Nn[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
         for (int i = 0; i < 3; ++i) {
             GemmProb& p = g.prob(m, Nn[i], slabs + off[i], 6 * H);
-            GemmBuilder::seg(p, w.embed_weight + (size_t)v0 * E, E, nullptr, Wih[i] + xoff, in1, E);
+            GemmBuilder::seg(p, w.embed_weight + (size_t)v0 * E, E, nullptr, Wih[i] + xoff, in1, E, nullptr, H2A_EMBED);
         }
         const int ns = g.finish(h);
         const long long stride = (long long)m * 6 * H;
@@ -628,13 +723,94 @@ extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t byte
     return 0;
 }
 
+// ---- f16x2 flavour (gemm_h2.h): fp16-pair images of the 14 weight matrices the GEMMs multiply by, their power-of-two scales, and the
+// bounds of the A operands that depend on the weights only (embedding rows, the sentinel vector).  fp32 stays the master copy.
+static const size_t H2_HEAD = 1024;      // bytes: exponent table | bound table | index scratch
+extern "C" size_t vsr_h2_weight_bytes(const vsr_handle* h) {
+    if (!h) return 0;
+    const float* p[B16_NW]; size_t n[B16_NW];
+    vsr_weights none;
+    memset(&none, 0, sizeof(none));
+    b16_weight_list(h->d, none, p, n);
+    size_t tot = H2_HEAD;
+    for (int i = 0; i < B16_NW; ++i) tot += ((n[i] + 7) & ~size_t(7)) * sizeof(float);
+    return tot + 256;
+}
+__global__ void k_h2_head_init(int* exps, unsigned* bounds, int* idx) {
+    const int i = threadIdx.x;
+    if (i < H2_NSLOT) {
+        exps[i] = 0;
+        bounds[i] = i == H2A_UNIT ? __float_as_uint(1.f) : 0u;
+        idx[i] = i; idx[H2_NSLOT + i] = -1; idx[2 * H2_NSLOT + i] = i;       // k_h2_exps: slot i from bound i alone
+    }
+}
+// exponents of the operands vsr_prepare*() measures: region rows (their max); the pooled descriptor (sum of <= R0 detection rows over a
+// count >= 1, step :126-128: R0 x the detections' max - loose bounds cost nothing, fp16 subnormals are honoured); the attended vector
+// (a convex combination of the sentinel and region rows, step :167-171): max(region max, sentinel bound)
+__global__ void k_h2_prepare_exps(const unsigned* __restrict__ bounds, int R0, int* __restrict__ exps) {
+    if (threadIdx.x != 0) return;
+    const float r = __uint_as_float(bounds[H2A_REGION]), dt = __uint_as_float(bounds[H2A_DET]), sn = __uint_as_float(bounds[H2B_SENT]);
+    exps[H2A_REGION] = h2_exp_of(r);
+    exps[H2A_DET] = h2_exp_of(dt * (float)R0);
+    exps[H2A_ATT] = h2_exp_of(fmaxf(r, sn));
+}
+extern "C" int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream) {
+    if (!h) return fail("vsr_refresh_h2_weights: null handle");
+    if (!buffer) {                                          // back to f32x3 for every launch
+        if (h->h2_on) { h->xproj = nullptr; invalidate_train_ctx(h->tc); h->prepared = false; }
+        h->h2_on = false;
+        h->h2.clear();
+        return 0;
+    }
+    if (!h->bound) return fail("vsr_refresh_h2_weights: weights not bound");
+    const vsr_dims& d = h->d;
+    if (d.det_feat_size % 8 || d.input_encoding_size % 8 || d.rnn_size % 8 || d.att_size % 8)
+        return fail("vsr_refresh_h2_weights: the f16x2 flavour needs det_feat_size, input_encoding_size, rnn_size and att_size to be "
+                    "multiples of 8 (whole 8-element groups of the fp16-pair images); got %d %d %d %d", d.det_feat_size, d.input_encoding_size, d.rnn_size, d.att_size);
+    if (bytes < vsr_h2_weight_bytes(h)) return fail("vsr_refresh_h2_weights: buffer too small");
+    if (reinterpret_cast<uintptr_t>(buffer) & 255) return fail("vsr_refresh_h2_weights: buffer must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const float* p[B16_NW]; size_t n[B16_NW];
+    b16_weight_list(h->d, h->w, p, n);
+    char* base = reinterpret_cast<char*>(buffer);
+    int* exps = reinterpret_cast<int*>(base);
+    unsigned* bounds = reinterpret_cast<unsigned*>(base + 128);
+    int* idx = reinterpret_cast<int*>(base + 256);          // 3 x H2_NSLOT ints of index lists for k_h2_exps
+    hipLaunchKernelGGL(k_h2_head_init, dim3(1), dim3(64), 0, s, exps, bounds, idx);
+    for (int i = 0; i < B16_NW; ++i)
+        hipLaunchKernelGGL(k_absmax, dim3(std::min<long long>(1024, cdiv((long long)n[i], 1024))), dim3(256), 0, s, p[i], (long long)n[i], bounds + i);
+    const long long ne = (long long)d.vocab_size * d.input_encoding_size;
+    hipLaunchKernelGGL(k_absmax, dim3(std::min<long long>(1024, cdiv(ne, 1024))), dim3(256), 0, s, h->w.embed_weight, ne, bounds + H2A_EMBED);
+    // |sentinel| = |s_fc s_t + b| <= max_d (sum_j |W_dj| + |b_d|) since |s_t| < 1                                   (step :155)
+    hipLaunchKernelGGL(k_row_l1_max, dim3(cdiv(d.det_feat_size, 4)), dim3(256), 0, s, h->w.s_fc_weight, h->w.s_fc_bias, d.det_feat_size, d.rnn_size, bounds + H2B_SENT);
+    hipLaunchKernelGGL(k_h2_exps, dim3(1), dim3(64), 0, s, bounds, idx, idx + H2_NSLOT, idx + 2 * H2_NSLOT, (int)H2A_REGION, exps);   // slots 0 .. 15
+    h->h2.clear();
+    float* out = reinterpret_cast<float*>(base + H2_HEAD);
+    for (int i = 0; i < B16_NW; ++i) {
+        const size_t n8 = (n[i] + 7) & ~size_t(7);
+        hipLaunchKernelGGL(k_f32_to_h2, dim3(cdiv((long long)n8, 8 * 256)), dim3(256), 0, s, p[i], reinterpret_cast<uint32_t*>(out), (long long)n8, exps, i);
+        h->h2.push_back(H2Range{p[i], p[i] + n[i], out, i});
+        out += n8;
+    }
+    LAUNCHCHK();
+    h->h2_exps = exps; h->h2_bounds = bounds;
+    if (!h->h2_on) { h->xproj = nullptr; invalidate_train_ctx(h->tc); }
+    h->prepared = false;              // the bounds of the region / detection operands are measured by vsr_prepare*()
+    h->h2_on = true;
+    return 0;
+}
+
 // fp32 GEMM flavour: 0 = exact k-ordered fma chain (v_mfma_f32_32x32x2_f32) for every launch,
 // 1 (default since round 3) = "f32x3" for launches of more than 192 rows: each fp32 operand split into three bf16 terms, six bf16
 // MFMAs per product, fp32 accumulation (gemm_f32x3.h).  Every reference fixture is checked in both (tests/conftest.py).
 extern "C" int vsr_set_gemm_mode(vsr_handle* h, int32_t mode) {
     if (!h) return fail("vsr_set_gemm_mode: null handle");
     if (mode != 0 && mode != 1) return fail("vsr_set_gemm_mode: mode %d not in {0, 1}", mode);
-    if (h->x3_on != (mode == 1)) h->xproj = nullptr;       // the decode cache is rebuilt in the new flavour
+    if (h->x3_on != (mode == 1)) {
+        h->xproj = nullptr;                                // the decode cache is rebuilt in the new flavour,
+        invalidate_train_ctx(h->tc);                       // a saved forward of the other flavour is not differentiated in this one,
+        h->prepared = false;                               // and the hoisted projections are redone: call vsr_prepare*() after a switch
+    }
     h->x3_on = mode == 1;
     return 0;
 }
@@ -696,7 +872,13 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     // (The index-list format reports its out-of-range count through the same read-back.)
     const long long rows = (long long)B * L * R;                         // slot entries
     const long long prows = indexed ? (long long)n_img * Rb : rows;      // rows att_va runs over
-    hipLaunchKernelGGL(k_rowmask, dim3(cdiv(prows, 4)), dim3(256), 0, s, regions, prows, D, c.bmask);
+    // f16x2 flavour: the bounds of the region / detection operands are measured in the passes that read them anyway (per-block maxima
+    // into the idle GEMM scratch, folded by one block); exponents of the region rows, the pooled descriptor and the attended vector
+    const bool h2b = h->h2_on;
+    float* bm_regions = h2b ? c.scratch : nullptr;
+    float* bm_det = h2b ? c.scratch + cdiv(prows, 4) : nullptr;
+    if (h2b && (size_t)(cdiv(prows, 4) + cdiv((long long)(indexed ? n_img : B) * R0, 4)) > c.scratch_floats) return fail("%s: scratch too small for the operand bounds", who);
+    hipLaunchKernelGGL(k_rowmask, dim3(cdiv(prows, 4)), dim3(256), 0, s, regions, prows, D, c.bmask, bm_regions);
     HIPCHK(hipMemsetAsync(c.nvalid_dev, 0, 4 * sizeof(int), s));      // [0] row count, [1] bad slot indices, [2] bad word / slot / verb ids
     if (indexed) {
         hipLaunchKernelGGL(k_index_rows, dim3(cdiv(rows, 256)), dim3(256), 0, s, slot_idx, row_img, c.bmask, B, L * R, Rb, n_img,
@@ -717,7 +899,12 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
 
     // pooled descriptor
     const long long drows = (long long)(indexed ? n_img : B) * R0;
-    hipLaunchKernelGGL(k_rowmask, dim3(cdiv(drows, 4)), dim3(256), 0, s, det, drows, D, c.dmask);
+    hipLaunchKernelGGL(k_rowmask, dim3(cdiv(drows, 4)), dim3(256), 0, s, det, drows, D, c.dmask, bm_det);
+    if (h2b) {
+        hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, s, bm_regions, (long long)cdiv(prows, 4), h->h2_bounds + H2A_REGION);
+        hipLaunchKernelGGL(k_max_reduce, dim3(1), dim3(1024), 0, s, bm_det, (long long)cdiv(drows, 4), h->h2_bounds + H2A_DET);
+        hipLaunchKernelGGL(k_h2_prepare_exps, dim3(1), dim3(64), 0, s, h->h2_bounds, R0, h->h2_exps);
+    }
     hipLaunchKernelGGL(k_pool, dim3(B, cdiv(D, 1024)), dim3(256), 0, s, det, indexed ? row_img : nullptr, c.dmask, R0, D, c.vbar);
     LAUNCHCHK();
 
@@ -727,11 +914,11 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     {
         GemmBuilder g;
         GemmProb& p0 = g.prob(B, 4 * H, c.scratch, 6 * H);
-        GemmBuilder::seg(p0, c.vbar, D, nullptr, w.lstm1_weight_ih + voff, in1, D);
+        GemmBuilder::seg(p0, c.vbar, D, nullptr, w.lstm1_weight_ih + voff, in1, D, nullptr, H2A_DET);
         GemmProb& p1 = g.prob(B, H, c.scratch + 4 * H, 6 * H);
-        GemmBuilder::seg(p1, c.vbar, D, nullptr, w.W1_is_weight + voff, in1, D);
+        GemmBuilder::seg(p1, c.vbar, D, nullptr, w.W1_is_weight + voff, in1, D, nullptr, H2A_DET);
         GemmProb& p2 = g.prob(B, H, c.scratch + 5 * H, 6 * H);
-        GemmBuilder::seg(p2, c.vbar, D, nullptr, w.W1_ig_weight + voff, in1, D);
+        GemmBuilder::seg(p2, c.vbar, D, nullptr, w.W1_ig_weight + voff, in1, D, nullptr, H2A_DET);
         const int ns = g.finish(h);
         const long long stride = (long long)B * 6 * H;
         for (int i = 0; i < 3; ++i) g.a.p[i].slab_stride = stride;
@@ -745,7 +932,7 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
         const int in2 = H + 2 * D;
         GemmBuilder g;
         GemmProb& p0 = g.prob(B, 4 * H, c.scratch, 4 * H);
-        GemmBuilder::seg(p0, c.vbar, D, nullptr, w.lstm2_weight_ih + H + D, in2, D);
+        GemmBuilder::seg(p0, c.vbar, D, nullptr, w.lstm2_weight_ih + H + D, in2, D, nullptr, H2A_DET);
         const int ns = g.finish(h);
         const long long stride = (long long)B * 4 * H;
         g.a.p[0].slab_stride = stride;
@@ -759,7 +946,7 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     if (c.nvalid > 0) {
         GemmBuilder g;
         GemmProb& p0 = g.prob(c.nvalid, A, c.scratch, A);
-        GemmBuilder::seg(p0, regions, D, c.vlist, w.att_va_weight, D, D);
+        GemmBuilder::seg(p0, regions, D, c.vlist, w.att_va_weight, D, D, nullptr, H2A_REGION);
         const int ns = g.finish(h);
         const long long stride = (long long)c.nvalid * A;
         if ((size_t)stride * ns > c.scratch_floats)
@@ -858,9 +1045,9 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
             const bool has_h2 = d.h2_first_lstm && io.t > 0, has_x = !xc, has_h1 = Whh[i] && io.t > 0;
             if (!has_h2 && !has_x && !has_h1) continue;
             GemmProb& p = g.prob(M, Nn[i], c.scratch + off[i], 6 * H);
-            if (has_h2) GemmBuilder::seg(p, h2o, H, io.parent, Wih[i], in1, H, h2o16);
-            if (has_x) GemmBuilder::seg(p, w.embed_weight, E, io.word_prev, Wih[i] + xoff, in1, E);
-            if (has_h1) GemmBuilder::seg(p, h1o, H, io.parent, Whh[i], H, H, h1o16);
+            if (has_h2) GemmBuilder::seg(p, h2o, H, io.parent, Wih[i], in1, H, h2o16, H2A_UNIT);
+            if (has_x) GemmBuilder::seg(p, w.embed_weight, E, io.word_prev, Wih[i] + xoff, in1, E, nullptr, H2A_EMBED);
+            if (has_h1) GemmBuilder::seg(p, h1o, H, io.parent, Whh[i], H, H, h1o16, H2A_UNIT);
             nblk = i == 0 ? 4 : i == 1 ? 5 : 6;
         }
         int ns = 0;
@@ -879,13 +1066,13 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         float* c2a = c.scratch;
         float* c2b_base;
         GemmProb& p0 = g.prob(M, H, c2a, H + A);
-        GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H, h1n16);
+        GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H, h1n16, H2A_UNIT);
         GemmProb& p1 = g.prob(M, A, c2a + H, H + A);
-        GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H, h1n16);
+        GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H, h1n16, H2A_UNIT);
         GemmProb& p2 = g.prob(M, D, nullptr, D + A);
-        GemmBuilder::seg(p2, c.s_t, H, nullptr, w.s_fc_weight, H, H, s_t16);
+        GemmBuilder::seg(p2, c.s_t, H, nullptr, w.s_fc_weight, H, H, s_t16, H2A_UNIT);
         GemmProb& p3 = g.prob(M, A, nullptr, D + A);
-        GemmBuilder::seg(p3, c.s_t, H, nullptr, w.att_sa_weight, H, H, s_t16);
+        GemmBuilder::seg(p3, c.s_t, H, nullptr, w.att_sa_weight, H, H, s_t16, H2A_UNIT);
         const int ns = g.finish(h);
         const long long stride_a = (long long)M * (H + A), stride_b = (long long)M * (D + A);
         c2b_base = c2a + stride_a * ns;
@@ -906,11 +1093,11 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     {
         GemmBuilder g;
         GemmProb& p0 = g.prob(M, 4 * H, c.scratch, 4 * H);
-        GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H, h1n16);
-        GemmBuilder::seg(p0, c.att, D, nullptr, w.lstm2_weight_ih + H, in2, D, att16);
-        if (io.t > 0) GemmBuilder::seg(p0, h2o, H, io.parent, w.lstm2_weight_hh, H, H, h2o16);
+        GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H, h1n16, H2A_UNIT);
+        GemmBuilder::seg(p0, c.att, D, nullptr, w.lstm2_weight_ih + H, in2, D, att16, H2A_ATT);
+        if (io.t > 0) GemmBuilder::seg(p0, h2o, H, io.parent, w.lstm2_weight_hh, H, H, h2o16, H2A_UNIT);
         GemmProb& p1 = g.prob(M, A, nullptr, A);
-        GemmBuilder::seg(p1, c.g_t, H, nullptr, w.att_ga_weight, H, H, g_t16);
+        GemmBuilder::seg(p1, c.g_t, H, nullptr, w.att_ga_weight, H, H, g_t16, H2A_UNIT);
         const int ns = g.finish(h);
         const long long stride = (long long)M * 4 * H, stride_g = (long long)M * A;
         g.a.p[0].slab_stride = stride;
@@ -929,7 +1116,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     {
         GemmBuilder g;
         GemmProb& p0 = g.prob(M, V, c.scratch, V);
-        GemmBuilder::seg(p0, h2n, H, nullptr, w.out_fc_weight, H, H, h2n16);
+        GemmBuilder::seg(p0, h2n, H, nullptr, w.out_fc_weight, H, H, h2n16, H2A_UNIT);
         int nblk = 0;
         if (io.s1_for_next) {
             // LSTM1 / gate sums of step t+1 over THIS step's rows: they depend on (h2, h1) only (the word enters through the
@@ -941,8 +1128,8 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
             for (int i = 0; i < 3; ++i) {
                 if (!d.h2_first_lstm && !Whh[i]) continue;
                 GemmProb& p = g.prob(M, Nn[i], c.pre1 + off[i], 6 * H);
-                if (d.h2_first_lstm) GemmBuilder::seg(p, h2n, H, nullptr, Wih[i], in1, H, h2n16);
-                if (Whh[i]) GemmBuilder::seg(p, h1n, H, nullptr, Whh[i], H, H, h1n16);
+                if (d.h2_first_lstm) GemmBuilder::seg(p, h2n, H, nullptr, Wih[i], in1, H, h2n16, H2A_UNIT);
+                if (Whh[i]) GemmBuilder::seg(p, h1n, H, nullptr, Whh[i], H, H, h1n16, H2A_UNIT);
                 nblk = i == 0 ? 4 : i == 1 ? 5 : 6;
             }
         }

@@ -18,17 +18,22 @@ from .CaptioningModel import CaptioningModel
 from vsrcap.engine import Engine
 
 
-# GEMM flavour a new model starts in.  'f32x3' since round 3: launches of more than 192 rows multiply on the bf16 matrix cores
-# with every fp32 operand split into three bf16 terms (csrc/gemm_f32x3.h); shorter launches stay on the exact fp32 fma chain.
-# The whole GPU suite runs in both flavours (tests/conftest.py parametrises this default), which is what admits it.
-DEFAULT_COMPUTE_DTYPE = 'f32x3'
+# GEMM flavour a new model starts in (all three keep fp32 operands in memory and accumulate in fp32):
+#   'f16x2' (round 4): every fp32 operand = two fp16 terms under a power-of-two scale, three MFMAs per product, weights pre-split into
+#           fp16-pair images per weight version (csrc/gemm_h2.h); the backward pass and sizes that are not multiples of 8 run as 'f32x3'
+#   'f32x3' (round 3): three bf16 terms per operand, six MFMAs per product (csrc/gemm_x3.h, gemm_x3s.h); launches of 129 .. 192 rows
+#           take the exact kernels (include/vsrcap.h, vsr_set_gemm_mode, has the routing)
+#   'f32':  the exact k-ordered fma chain for every launch
+# The whole GPU suite runs in every one of them (tests/conftest.py parametrises this default), which is what admits a default.
+DEFAULT_COMPUTE_DTYPE = 'f16x2'
+COMPUTE_DTYPES = ('f32', 'f32x3', 'f16x2', 'bf16')
 
 
 def set_default_compute_dtype(dtype):
-    """compute dtype of models constructed from now on ('f32' = exact fma chain everywhere, 'f32x3', 'bf16'); returns the old one"""
+    """compute dtype of models constructed from now on ('f32' = exact fma chain everywhere, 'f32x3', 'f16x2', 'bf16'); returns the old one"""
     global DEFAULT_COMPUTE_DTYPE
-    if dtype not in ('f32', 'bf16', 'f32x3'):
-        raise ValueError("compute dtype must be 'f32', 'f32x3' or 'bf16'")
+    if dtype not in COMPUTE_DTYPES:
+        raise ValueError("compute dtype must be one of %s" % (COMPUTE_DTYPES,))
     old, DEFAULT_COMPUTE_DTYPE = DEFAULT_COMPUTE_DTYPE, dtype
     return old
 
@@ -88,14 +93,14 @@ class ControllableCaptioningModel(CaptioningModel):
         self.compute_dtype = os.environ.get('VSR_COMPUTE_DTYPE', DEFAULT_COMPUTE_DTYPE)
 
     def set_compute_dtype(self, dtype):
-        """'f32x3' (default): fp32 operands and fp32 accumulation; launches of more than 192 rows form their products on the
-        bf16 matrix cores (each fp32 operand split into three bf16 terms, six MFMAs per product; csrc/gemm_f32x3.h), the rest
-        on the exact fma chain.  Token parity and the 1e-4 loss bound hold (every GPU test runs in this flavour and in 'f32').
+        """'f16x2' (default) / 'f32x3': fp32 operands and fp32 accumulation, products formed on the fp16 / bf16 matrix cores from two /
+        three terms per operand (three / six MFMAs per product; csrc/gemm_h2.h / gemm_x3.h; the module comment above and
+        include/vsrcap.h have the routing).  Token parity and the 1e-4 loss bound hold (every GPU test runs in each flavour).
         'f32': the exact k-ordered fp32 fma chain (v_mfma_f32_32x32x2_f32) for every launch.
         'bf16': throughput mode - matrix products take bf16 operands with fp32 accumulation (v_mfma_f32_32x32x16_bf16);
         parameters, optimizer state, states and reductions stay fp32.  Not a parity mode."""
-        if dtype not in ('f32', 'bf16', 'f32x3'):
-            raise ValueError("compute dtype must be 'f32', 'f32x3' or 'bf16'")
+        if dtype not in COMPUTE_DTYPES:
+            raise ValueError("compute dtype must be one of %s" % (COMPUTE_DTYPES,))
         self.compute_dtype = dtype
         return self
 
@@ -143,7 +148,9 @@ class ControllableCaptioningModel(CaptioningModel):
             raise RuntimeError("model parameters are on %s but the inputs are on %s" % (pdev, device))
         self._eng.bind(params)
         self._eng.set_bf16(pdev, self._weights_version(), self.compute_dtype == 'bf16')
-        self._eng.set_gemm_mode(self.compute_dtype == 'f32x3')
+        self._eng.set_gemm_mode(self.compute_dtype in ('f32x3', 'f16x2'))
+        dims8 = all(v % 8 == 0 for v in (self.det_feat_size, self.input_encoding_size, self.rnn_size, self.att_size))
+        self._eng.set_h2(pdev, self._weights_version(), self.compute_dtype == 'f16x2' and dims8)      # (other sizes: plain f32x3)
         # inference keeps a weight-only cache (embedding projection); while training the weights move every step
         self._eng.decode_cache(pdev, self._weights_version(), enable=not self.training)
         return self._eng

@@ -75,6 +75,8 @@ SIGNATURES = {
     "vsr_bf16_weight_bytes": (SZ, [P]),
     "vsr_refresh_bf16_weights": (I32, [P, P, SZ, P]),
     "vsr_set_gemm_mode": (I32, [P, I32]),
+    "vsr_h2_weight_bytes": (SZ, [P]),
+    "vsr_refresh_h2_weights": (I32, [P, P, SZ, P]),
     "vsr_workspace_bytes": (SZ, [P, I32, I32, I32, I32, I32]),
     "vsr_prepare": (I32, [P, P, I32, I32, P, I32, I32, I32, P, SZ, P]),
     "vsr_workspace_bytes_indexed": (SZ, [P, I32, I32, I32, I32, I32, I32, I32]),

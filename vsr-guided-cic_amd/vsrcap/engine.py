@@ -99,6 +99,8 @@ class Engine:
         self._cache_key = None
         if getattr(self, "_bf16_key", None) is not None:
             self._bf16_key = ("stale",)          # bf16 mode stays on; the copies are rebuilt by the next set_bf16()
+        if getattr(self, "_h2_key", None) is not None:
+            self._h2_key = ("stale",)            # ... and so are the fp16-pair images
 
     def raise_on_bad_ids(self, device, who):
         if not self.check_ids:
@@ -125,14 +127,33 @@ class Engine:
         _lib.check(self.lib.vsr_set_verb_table(self.h, _ptr(rp), _ptr(fl), n))
 
     def set_gemm_mode(self, x3):
-        """True (the library's default): "f32x3" for launches of more than 192 rows (three bf16 terms per fp32 operand,
-        include/vsrcap.h); False: the exact fp32 fma chain for every launch"""
+        """True (the library's default): "f32x3" - three bf16 terms per fp32 operand, six MFMAs per product; which kernel a launch
+        takes depends on its rows (include/vsrcap.h, vsr_set_gemm_mode); False: the exact fp32 fma chain for every launch"""
         x3 = bool(x3)
         if x3 != getattr(self, "_x3", True):
             _lib.check(self.lib.vsr_set_gemm_mode(self.h, 1 if x3 else 0))
             self._x3 = x3
             self._cache_key = None
             self._prep_key = None
+
+    # ------------------------------------------------------------------ f16x2: fp16-pair weight images on top of f32x3
+    @_on_device
+    def set_h2(self, device, weights_version, enable):
+        """enable: (re)build the fp16-pair images of the weight matrices when the bound weights or their version changed
+        (include/vsrcap.h, vsr_refresh_h2_weights); disable: back to plain f32x3."""
+        key = (self._bound_ptrs, weights_version) if enable else None
+        if key == getattr(self, "_h2_key", None):
+            return
+        if not enable:
+            _lib.check(self.lib.vsr_refresh_h2_weights(self.h, C.c_void_p(0), 0, self._stream(device)))
+        else:
+            n = self.lib.vsr_h2_weight_bytes(self.h)
+            if getattr(self, "_h2_buf", None) is None or self._h2_buf.numel() < n or self._h2_buf.device != device:
+                self._h2_buf = torch.empty(n, dtype=torch.uint8, device=device)      # (torch allocations are 512-byte aligned)
+            _lib.check(self.lib.vsr_refresh_h2_weights(self.h, _ptr(self._h2_buf), self._h2_buf.numel(), self._stream(device)))
+        self._cache_key = None                   # the library voids the decode cache and the hoisted tensors on every refresh
+        self._prep_key = None
+        self._h2_key = key
 
     # ------------------------------------------------------------------ bf16 throughput mode
     @_on_device
