@@ -331,8 +331,9 @@ def decode_bench(args, D, torch, dist, synth):
     # equally often); an event pair on EVERY launch costs the timed region 3 %
     eng.profile_begin(every=PROFILE_EVERY)
     t0 = time.perf_counter()
+    last_ids = None
     for i in range(args.steps):
-        one_step(i)
+        last_ids = one_step(i)
     D.barrier()
     dt = time.perf_counter() - t0
     gemm_seen = eng.profile_seen()
@@ -359,6 +360,8 @@ def decode_bench(args, D, torch, dist, synth):
                                    "240 MB, built once per weight version outside the timed call; all per-image hoisting is inside)"},
         "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic, tsrc, gemm_bytes),
     }
+    if getattr(args, "emit_ids", False) and rank == 0:
+        line["config"]["ids"] = last_ids.cpu().tolist()
     if indexed and rank == 0:
         dense = [(d, r.dense().contiguous()) for d, r in batches]
         with torch.no_grad():
@@ -485,6 +488,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=12)
     ap.add_argument("--cpu-full", type=int, default=1, help="1: the CPU baseline's value is ONE as-written call at the workload's own batch size (0: the bounded sample only)")
     ap.add_argument("--batch", type=int, default=0, help="images per batch instead of 100 (experiments only: not the BASELINE workload)")
+    ap.add_argument("--emit-ids", action="store_true", help="decode workloads: put the (B, T) word ids of the last timed step into config.ids (tests compare a sharded run with a single-process run)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (the measurement); gloo = self-test of the multi-rank path on fewer GPUs than ranks")
     args = ap.parse_args()

@@ -13,11 +13,11 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(*extra):
+def _bench(*extra, gpus=2, steps=2):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--backend", "gloo", "--steps", str(steps), "--warmup", "1",
            "--no-cpu", "--no-secondary", "--no-alt"] + list(extra)
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -40,4 +40,30 @@ def test_bench_two_ranks_decode(scaling):
 def test_bench_two_ranks_xe_step():
     line = _bench("--workload", "xe")
     assert line["n_gpus"] == 2 and line["config"]["rccl_world_size_observed"] == 2
+    assert line["unit"] == "samples/s" and line["value"] > 0
+
+
+def test_bench_eight_ranks_strong_scaled_decode_equals_the_single_process_ids():
+    """the driver's 8-GPU SCALE run, as far as one GPU can rehearse it: bench.py --gpus 8 --scaling strong starts 8 rank processes (all on
+    this GPU, collectives through gloo), every rank decodes its 13- or 12-image shard of ONE batch of 100 through the HIP path
+    (beams never cross images, CaptioningModel.py:107-109), rank 0 gathers the (100, T) ids - which must be the ids one process
+    decodes for the whole batch (a 13-image launch takes other kernels than a 100-image launch: rows may differ only where the
+    synthetic inputs leave two candidates within rounding of each other)."""
+    import numpy as np
+    eight = _bench("--scaling", "strong", "--emit-ids", gpus=8, steps=1)
+    assert eight["n_gpus"] == 8 and eight["config"]["rccl_world_size_observed"] == 8 and eight["scaling"] == "strong"
+    assert eight["config"]["batch_per_gpu"] == 13              # rank 0's shard of 13,13,13,13,12,12,12,12
+    one = _bench("--emit-ids", gpus=1, steps=1)
+    a, b = np.array(eight["config"]["ids"]), np.array(one["config"]["ids"])
+    assert a.shape == b.shape == (100, 20)
+    same = (a == b).all(1)
+    print("8 shards vs 1 process: %d of 100 captions identical" % same.sum())
+    assert same.mean() >= 0.97, np.nonzero(~same)[0]
+
+
+def test_bench_eight_ranks_xe_step_bf16_wire():
+    """configs[3] as the driver would launch it on 8 GPUs, rehearsed on one: 8 ranks, uneven shards of the batch of 100, bf16 compute,
+    bf16 gradients on the wire (all-to-all + fp32 sum + all-gather, vsrcap/parallel.py), global loss normalisation."""
+    line = _bench("--workload", "xe", "--dtype", "bf16", gpus=8, steps=1)
+    assert line["n_gpus"] == 8 and line["config"]["rccl_world_size_observed"] == 8
     assert line["unit"] == "samples/s" and line["value"] > 0

@@ -97,13 +97,15 @@ def _wide_errors(dtypes, scale_regions=1.0, scale_weights=1.0):
     o64 = vo.Oracle(w, cfg["T"], 2, as_written=False, dtype=torch.float64)
     with torch.no_grad():
         ref, refg = o64.forward(det.double(), caps, ctrl_seq.double())
-    errs = {}
+    errs, outs = {}, {}
     for dt in dtypes:
         m = helpers.build_model(cfg, w, DEV, bos=meta["bos"]).set_compute_dtype(dt)
         with torch.no_grad():
             out, gate = m((det.to(DEV),), (caps.to(DEV), ctrl_seq.to(DEV)))
         assert torch.isfinite(out).all() and torch.isfinite(gate).all(), dt
         errs[dt] = max((out.cpu().double() - ref).abs().max().item(), (gate.cpu().double() - refg).abs().max().item())
+        outs[dt] = out.cpu()
+    errs["_outs"] = outs
     return errs
 
 
@@ -113,7 +115,11 @@ def test_h2_error_against_fp64_next_to_the_fma_chain_and_f32x3(monkeypatch):
     monkeypatch.setenv("VSR_X3_MIN_ROWS", "1")
     errs = _wide_errors(("f32", "f32x3", "f16x2"))
     print("max |log-prob error| vs fp64: fma chain %.3e, f32x3 %.3e, f16x2 %.3e" % (errs["f32"], errs["f32x3"], errs["f16x2"]))
-    assert errs["f16x2"] != errs["f32"] and errs["f16x2"] != errs["f32x3"], "the f16x2 kernels did not run"
+    # (the MAXIMUM can coincide between flavours - it sits on one log-prob whose final fp32 rounding dominates - the outputs cannot)
+    o = errs["_outs"]
+    n32, n3 = (o["f16x2"] != o["f32"]).sum().item(), (o["f16x2"] != o["f32x3"]).sum().item()
+    print("log-probs that differ in their last bits: f16x2 vs fma chain %d, f16x2 vs f32x3 %d of %d" % (n32, n3, o["f32"].numel()))
+    assert n32 > 0 and n3 > 0, "the f16x2 kernels did not run"
     assert errs["f16x2"] <= 1.5 * errs["f32"] + 1e-6 and errs["f16x2"] < 5e-5
 
 

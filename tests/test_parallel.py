@@ -110,26 +110,24 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch():
 
 
 # ---- bf16 wire format of the gradient exchange (BASELINE configs[3]: "bf16 ... RCCL grad all-reduce"): fp32 gradients are rounded to
-# bf16 only for the collective; the summed result goes back into the fp32 buffer the optimizer reads
+# bf16 only for the collective (all-to-all of shards, fp32 sum by the shard owner, one more rounding, all-gather); the result goes back
+# into the fp32 buffer the optimizer reads
+CFG8 = dict(V=37, B=11, R0=6, R=5, D=64, L=4, T=6, E=16, H=24, A=12)      # 11 images on 8 ranks: 2,2,2,1,1,1,1,1
+
+
 def _worker_bf16(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    cfg = CFG
+    cfg = CFG8
     det, seq, caps, gts = helpers.train_inputs(cfg, 9)
     lo, hi = parallel.shard_bounds(cfg["B"], world, rank)
     out = {}
     for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
         o, params = _make(cfg)
         opt = torch.optim.SGD(params, lr=0.0)           # lr 0: the step leaves the exchanged gradients in .grad for inspection
-
-        def host_sum(t):                                # gloo's own bf16 support varies by build: sum in fp32 what the wire carried
-            c = t.float()
-            dist.all_reduce(c)
-            t.copy_(c)
-        step = parallel.DataParallelStep(params, opt, forward_fn=lambda d, c, s: o.forward(d, c, s), exchange_dtype=dt,
-                                         all_reduce_fn=host_sum if dt == torch.bfloat16 else None)
+        step = parallel.DataParallelStep(params, opt, forward_fn=lambda d, c, s: o.forward(d, c, s), exchange_dtype=dt)
         step.xe_step(det[lo:hi], caps[lo:hi], seq[lo:hi], gts[lo:hi])
         out[name] = torch.cat([p.grad.reshape(-1) for p in params]).clone()
     if rank == 0:
@@ -137,17 +135,27 @@ def _worker_bf16(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_bf16_gradient_exchange_rounds_only_the_wire():
+def _bf16_wire_deviation(world):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_bf16, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_worker_bf16, args=(world, _free_port(), ret), nprocs=world, join=True)
     a, b = ret["f32"], ret["bf16"]
     assert not np.array_equal(a, b), "the bf16 wire format was not used"
-    # each rank's share is rounded to 8 mantissa bits (relative 2^-9 per term) and the sum once more
-    scale = np.abs(a).max()
-    assert np.abs(a - b).max() <= 3 * 2.0 ** -9 * scale
-    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
-    assert cos > 0.99999, cos
-    # every exchanged value is exactly representable in bf16 (the wire carried bf16 and the host sum was rounded back)
     bt = torch.from_numpy(b)
-    assert torch.equal(bt.bfloat16().float(), bt)
+    assert torch.equal(bt.bfloat16().float(), bt)        # every exchanged value is a bf16 value (the sum was rounded back once)
+    scale = np.abs(a).max()
+    cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+    return np.abs(a - b).max() / scale, float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((a ** 2).mean())), cos
+
+
+def test_bf16_gradient_exchange_rounds_only_the_wire_and_does_not_degrade_with_the_world_size():
+    """the deviation of the exchanged gradient from the fp32 exchange, STATED at world 2 and at world 8 (uneven shards): every value is
+    rounded twice - each rank's share (relative 2^-9 per term), the fp32 sum once more - whatever the world size, so world 8 must stay
+    within sqrt(7) of world 2 (a ring that sums in bf16 commits up to 7 roundings per element there)."""
+    m2, r2, c2 = _bf16_wire_deviation(2)
+    m8, r8, c8 = _bf16_wire_deviation(8)
+    print("bf16 wire vs fp32 exchange: world 2 max %.3e of the largest gradient, rms %.3e, cosine %.7f; world 8 max %.3e, rms %.3e, cosine %.7f"
+          % (m2, r2, c2, m8, r8, c8))
+    assert m2 <= 3 * 2.0 ** -9 and m8 <= 3 * 2.0 ** -9
+    assert c2 > 0.99999 and c8 > 0.99999
+    assert r8 <= np.sqrt(7.0) * r2 + 1e-6

@@ -65,7 +65,7 @@ struct Ctx {
     int nvalid = 0;
     float* st[2][4];   // h1, c1, h2, c2 double-buffered
     int *slot[2], *word[2], *gate[2], *parent;
-    float *s_t, *gpre, *g_t, *hA, *sa, *sent, *att, *zsum, *lg, *top_v;
+    float *s_t, *gpre, *g_t, *hA, *sa, *sent, *att, *zsum, *lg, *top_v, *alpha;
     float* ga_slabs;             // att_ga(g_t) partial sums: kept apart from `scratch`, the vocabulary GEMM overwrites that first
     int* top_i;
     float *seq[2], *mask[2];
@@ -228,6 +228,7 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     c.sent = b.take<float>(M * D);
     c.att = b.take<float>(M * D);
     c.zsum = b.take<float>(M);
+    c.alpha = b.take<float>(M * (c.R + 1));
     c.lg = b.take<float>(M * 2);
     c.ga_slabs = b.take<float>(M * A * 8);
     c.top_v = b.take<float>(M * KMAX);
@@ -1083,10 +1084,17 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         // k_gate2's work (g_t, hA, s_a, sentinel from the S2 slabs) is done by the attention kernel's row blocks themselves
         const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16};
         const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
-        if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16);
-        else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16);
+        // scores + softmax per row (alpha and the sentinel go to memory), then the weighted sums per IMAGE: hypotheses on the same slot
+        // share the region rows they read (one workgroup per row read them from L2 once per hypothesis: 200 MB per beam-5 launch)
+        float* alpha = io.alpha_out ? io.alpha_out : c.alpha;
+        if (D >= 2048) hipLaunchKernelGGL((k_attend<512, true>), dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, alpha, att16, c.sent);
+        else hipLaunchKernelGGL((k_attend<256, true>), dim3(cdiv(M, 8) * 8), dim3(256), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, alpha, att16, c.sent);
+        const int nimg = M / io.rpi;
+        const size_t wsm = (size_t)io.rpi * (2 * c.R + 2) * sizeof(float);
+        hipLaunchKernelGGL(k_attend_wsum<128>, dim3(cdiv(nimg, 8) * 8, cdiv(D, 512)), dim3(128), wsm, s, alpha, c.sent, c.regions, c.ridx, io.slot, io.fixed_slot,
+                           io.rpi, nimg, c.L, c.R, D, c.att, att16);
     }
     // ---- S5
     GateLogitArgs gate_args;

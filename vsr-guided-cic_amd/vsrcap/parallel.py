@@ -87,9 +87,9 @@ class DataParallelStep:
     sample_fn(det, ctrl) -> ((words, gates), (lp_w, lp_g)).
     all_reduce_fn(tensor) -> None: override of the SUM collective (tests: gloo through host memory).
     exchange_dtype: torch.float32 (default) or torch.bfloat16 - the wire format of the gradient exchange (BASELINE configs[3] names
-    bf16: 142 MB instead of 285 MB per step over xGMI).  With bf16 every bucket is rounded to a persistent bf16 image, that image is
-    all-reduced, and the sum is written back into the fp32 flat buffer the optimizer reads: gradients, Adam state and master
-    weights stay fp32, only the exchanged values carry 8 mantissa bits."""
+    bf16: 142 MB instead of 285 MB per step over xGMI).  With bf16 every bucket is rounded to a bf16 image, the images are exchanged
+    shard-wise (all-to-all), summed in fp32 by the shard's owner, rounded once more and all-gathered into the fp32 flat buffer the
+    optimizer reads: gradients, Adam state and master weights stay fp32, an exchanged value is rounded twice whatever the world size."""
 
     def __init__(self, model_or_params, optimizer, forward_fn=None, sample_fn=None, group=None, all_reduce_fn=None,
                  exchange_dtype=torch.float32):
@@ -102,7 +102,8 @@ class DataParallelStep:
         if exchange_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("exchange_dtype must be torch.float32 or torch.bfloat16")
         self.exchange_dtype = exchange_dtype
-        self._wire = None                  # bf16 image of the flat gradient buffer (exchange_dtype = bf16)
+        self._wire = None                  # bf16 image of the flat gradient buffer (exchange_dtype = bf16, caller-supplied SUM)
+        self._wires = {}                   # per bucket size: (send, recv, out) bf16 staging of the all-to-all exchange
         if self.model is not None:
             from . import _lib
             sd = dict(self.model.named_parameters())
@@ -149,17 +150,33 @@ class DataParallelStep:
                 return None
             return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         g = self.grads
-        if self._wire is None or self._wire.numel() != g.flat.numel() or self._wire.device != g.flat.device:
-            self._wire = torch.empty(g.flat.numel(), dtype=torch.bfloat16, device=g.flat.device)
-        lo = buf.data_ptr() - g.flat.data_ptr()
-        lo //= g.flat.element_size()
-        wire = self._wire[lo:lo + buf.numel()]
-        wire.copy_(buf)                                         # round to nearest even
         if self.all_reduce_fn is not None:
+            # caller-supplied SUM (tests that stage the collective through host memory): the bf16 image itself is summed
+            if self._wire is None or self._wire.numel() != g.flat.numel() or self._wire.device != g.flat.device:
+                self._wire = torch.empty(g.flat.numel(), dtype=torch.bfloat16, device=g.flat.device)
+            lo = (buf.data_ptr() - g.flat.data_ptr()) // g.flat.element_size()
+            wire = self._wire[lo:lo + buf.numel()]
+            wire.copy_(buf)                                     # round to nearest even
             self.all_reduce_fn(wire)
-        else:
-            dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)      # stream-ordered on this (side) stream
-        buf.copy_(wire)
+            buf.copy_(wire)
+            return None
+        # bf16 on the wire, fp32 in the sum: every rank sends shard r of its bf16 image to rank r (all-to-all: on the fully connected
+        # xGMI mesh every pair has its own link), rank r adds the `world` contributions in fp32 in rank order, rounds the sum to bf16
+        # once, and the shards are all-gathered.  Same bytes per link as a ring all-reduce of the bf16 image (2 (N-1)/N x 142 MB),
+        # but an element is rounded TWICE whatever the world size - a ring that sums in bf16 rounds it up to N times
+        # (tests/test_parallel.py states the deviation at world 2 and 8).
+        world = self._world()
+        n = buf.numel()
+        shard = (n + world - 1) // world
+        key = (n, world, buf.device)
+        if key not in self._wires:
+            self._wires[key] = tuple(torch.zeros(world * shard, dtype=torch.bfloat16, device=buf.device) for _ in range(3))
+        send, recv, out = self._wires[key]
+        send[:n].copy_(buf)                                     # round to nearest even (the padding stays zero)
+        dist.all_to_all_single(recv, send, group=self.group)    # stream-ordered on this (side) stream
+        red = recv.view(world, shard).float().sum(0).to(torch.bfloat16)
+        dist.all_gather_into_tensor(out, red, group=self.group)
+        buf.copy_(out[:n])
         return None
 
     def _backward_and_exchange(self, loss):
