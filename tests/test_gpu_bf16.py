@@ -56,11 +56,13 @@ def test_bf16_xe_forward_and_gradients_wide():
 
 def test_bf16_xe_step_batch100_full_size_deviation():
     """configs[3] as BASELINE.json states it (XE, batch 100, bf16) at the full sizes - B = 100, T = 20, E = H = 1000, D = 2048,
-    V = 10 000: the bf16 throughput mode next to the fp32 parity path on the reference fixture g1_xe_b100.  STATED deviations
-    (observed values are printed; first run: loss 19.1226 vs 19.1390, word NLL 9.21227 vs 9.21226, gate NLL 2.4776 vs 2.4817 - the
-    two gate logits are differences of large raw scores): total loss within 3e-2 absolute of the reference's, word NLL within 5e-3,
-    gate NLL within 8e-3, every one of the 28 gradients with cosine
-    >= 0.995 against the fp32 gradient and norm within 4 % (observed worst: 2.0 %, the 512-element att_s.weight), arg-max of the word log-probs equal on >= 98 % of the 2000 rows (observed 98.9 %)."""
+    V = 10 000: the bf16 throughput mode next to the fp32 parity path on the reference fixture g1_xe_b100.  STATED deviations, bounds =
+    1.5 x the values observed on the box (profiles/r04_c_bf16_hoisted_projection_fp32_vs_bf16.txt).  Since round 4 the hoisted
+    att_va(regions) projection stays fp32-equivalent in this mode (the shift logit sums up to 36 of its RAW scores, step :187: bf16
+    rounding added up coherently there): total loss 19.13909 vs the reference's 19.13897 (1.2e-4; with that GEMM in bf16: 19.1225,
+    1.6e-2 and a gate-NLL bias of 4e-3), max |d log-prob| 5.4e-4 on words and 3.0e-2 on gates (was 5.6e-2), arg-max of the word
+    log-probs equal on 99.15 % of the 2000 rows, every one of the 28 gradients with cosine >= 0.9998 against the fp32 gradient (worst:
+    the 512-element att_s.weight) and norm within 2.2 %."""
     meta, g = load_golden("g1_xe_b100")
     cfg = meta["cfg"]
     assert cfg["B"] == 100 and cfg["V"] == 10000 and cfg["H"] == 1000
@@ -80,11 +82,13 @@ def test_bf16_xe_step_batch100_full_size_deviation():
                    out.detach().clone(), gate.detach().clone())
     (a32, l32, gr32, o32, g32), (a16, l16, gr16, o16, g16) = res["f32"], res["bf16"]
     assert abs(l32[0] - g["losses"][0]) < 1e-4                       # the fp32 pass is the parity path
-    assert abs(l16[0] - g["losses"][0]) < 3e-2 and abs(l16[1] - g["losses"][1]) < 5e-3 and abs(l16[2] - g["losses"][2]) < 8e-3, (l16, g["losses"])
+    print("bf16 losses (total, words, gates) %s vs the reference's %s" % (l16, tuple(float(x) for x in g["losses"])))
+    assert abs(l16[0] - g["losses"][0]) < 6e-4 and abs(l16[1] - g["losses"][1]) < 1e-3 and abs(l16[2] - g["losses"][2]) < 1e-3, (l16, g["losses"])
     d_out, d_gate = (o16 - o32).abs().max().item(), (g16 - g32).abs().max().item()
     assert d_out > 1e-6, "the bf16 kernels did not run"
+    assert d_out < 8.1e-4 and d_gate < 4.5e-2, (d_out, d_gate)
     agree = (a16 == a32).float().mean().item()
-    assert agree >= 0.98, agree
+    assert agree >= 0.985, agree
     worst, worst_k, worst_n = 1.0, None, 0.0
     for k in gr32:
         a, b = gr32[k], gr16[k]
@@ -93,8 +97,8 @@ def test_bf16_xe_step_batch100_full_size_deviation():
         if cos < worst:
             worst, worst_k = cos, k
         worst_n = max(worst_n, rn)
-        assert cos >= 0.995, (k, cos)
-        assert rn < 0.04, (k, rn)
+        assert cos >= 0.9997, (k, cos)
+        assert rn < 0.033, (k, rn)
     print("bf16 vs fp32 at B=100 / V=10000: loss %.6f vs %.6f (reference %.6f), max |dlogp| words %.3e gates %.3e, arg-max agreement "
           "%.4f, worst gradient cosine %.6f (%s), worst norm deviation %.4f" % (l16[0], l32[0], g["losses"][0], d_out, d_gate, agree, worst, worst_k, worst_n))
 

@@ -135,7 +135,7 @@ __device__ __forceinline__ int h2_prob_exp(const GemmArgs& args, const GemmProb&
     return S < -120 ? -120 : (S > 120 ? 120 : S);
 }
 
-constexpr size_t h2_lds_bytes(int TM, int TN) { return (size_t)2 * 2 * (128 + 32 * TN * (8 / (4 / TM))) * H2_ROW * sizeof(uint16_t); }
+constexpr size_t h2_lds_bytes(int TM, int TN) { return (size_t)2 * 2 * ((128 + 32 * TN * (8 / (4 / TM))) * H2_ROW + 32) * sizeof(uint16_t); }
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Wide kernel.  16 waves: waves 0-7 MULTIPLY (WM x WN waves, TM x TN 32x32 tiles each), waves 8-15 MOVE: asynchronous global loads two
@@ -148,7 +148,10 @@ void gemm_nt_h2_kernel(const GemmArgs args) {
     constexpr int WM = 4 / TM, WN = 8 / WM;
     constexpr int BM = 128, BN = 32 * TN * WN, BK = H2_BK;
     static_assert(32 * TM * WM == BM, "tile shape");
-    constexpr int PLANE = (BM + BN) * H2_ROW;             // fp16 elements per plane
+    // fp16 elements per plane: (BM + BN) rows of 64 bytes, + 64 bytes so that the lo plane starts 16 banks after the hi plane - the eight
+    // lanes that store one weight row (four k groups x {hi, lo}) then cover 32 different banks (without the pad the hi and lo chunk of a
+    // group collided two ways on every ds_write_b128: SQ_LDS_BANK_CONFLICT was 22 % of the LDS cycles, profiles/r04_b_h2_wide_sq_tcc_counters_M500.txt)
+    constexpr int PLANE = (BM + BN) * H2_ROW + 32;
     constexpr int BUF = 2 * PLANE;                        // hi | lo
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];
 
@@ -164,17 +167,13 @@ void gemm_nt_h2_kernel(const GemmArgs args) {
     const bool mover = wave >= 8;
     const int r = lane & 31, hh = lane >> 5;
 
-    // accumulator exponent of every problem of the launch, once (static indices: a run-time problem index into the argument struct
-    // made hipcc copy the whole struct to scratch)
-    int pS[4];
+    // accumulator exponent of every problem of the launch, once, packed as four signed bytes of ONE register (static indices into the
+    // argument struct: a run-time problem index made hipcc copy the whole struct to scratch; and a 4-element array of them went to
+    // scratch itself, whose loads share vmcnt with the asynchronous tile loads)
+    unsigned pS = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pS[i] = i < args.nprob ? h2_prob_exp(args, args.p[i]) : 0;
-    auto exp_of_prob = [&](int p) __attribute__((always_inline)) {
-        int s = pS[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) s = (p == i) ? pS[i] : s;
-        return s;
-    };
+    for (int i = 0; i < 4; ++i) pS |= (unsigned)((i < args.nprob ? h2_prob_exp(args, args.p[i]) : 0) & 0xff) << (8 * i);
+    auto exp_of_prob = [&](int p) __attribute__((always_inline)) { return (int)(pS << (24 - 8 * p)) >> 24; };
 
     int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0;
     bool c_last = false;

@@ -370,10 +370,11 @@ struct Gate2Args {
     uint16_t* g_t16 = nullptr;      // optional bf16 image of g_t (bf16 GEMM mode)
 };
 
-// SPLIT: the kernel stops behind the softmax - alpha goes to alpha_out, the sentinel (fused path) to sent_out - and
-// k_attend_wsum below forms the weighted sums PER IMAGE (the hypotheses of an image that sit on the same slot share every region
-// row they read; one workgroup per row re-read them from L2 for each of the five hypotheses: 200 MB per beam-5 launch)
-template <int NT, bool SPLIT = false>
+// (Round 4 measured the split the round-3 review asked for - this kernel stopping behind the softmax, a second kernel forming the weighted
+// sums per IMAGE so that hypotheses on one slot share the region rows they read: bit-identical, and SLOWER end to end, 297.8 k against
+// 345.5 k tokens/s beam-5 in one run (profiles/r04_d_attention_split_ab.txt): the scores kernel alone takes 22.7 of the fused kernel's 31 us,
+// the weighted sums were never its long pole, and the second launch adds its own dependent round trips.  Not kept.)
+template <int NT>
 __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* __restrict__ hA, const float* __restrict__ sa,
                                                 const float* __restrict__ sent, const float* __restrict__ P,
                                                 const float* __restrict__ regions, const float* __restrict__ rmask,
@@ -382,8 +383,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                                                 int R, int A, int D, const float* __restrict__ w_a,
                                                 const float* __restrict__ w_s, float* __restrict__ att,
                                                 float* __restrict__ zsum, float* __restrict__ alpha_out,
-                                                uint16_t* __restrict__ att16 = nullptr /* optional bf16 image of att */,
-                                                float* __restrict__ sent_out = nullptr /* SPLIT + fused: (M, D) sentinel rows */) {
+                                                uint16_t* __restrict__ att16 = nullptr /* optional bf16 image of att */) {
     extern __shared__ float sm[];
     float* hA_s = sm;             // A
     float* sa_s = hA_s + A;       // A   (fused gate2 only)
@@ -444,7 +444,6 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                     const float4 bs = *reinterpret_cast<const float4*>(g2.b_sfc + cc);
                     s.x += bs.x; s.y += bs.y; s.z += bs.z; s.w += bs.w;
                     *reinterpret_cast<float4*>(sent_s + cc) = s;
-                    if constexpr (SPLIT) *reinterpret_cast<float4*>(sent_out + (long long)row * D + cc) = s;
                 } else {
                     *reinterpret_cast<float4*>(sa_s + (cc - D)) = s;
                 }
@@ -463,7 +462,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
             }
             for (int cc = tid; cc < D + A; cc += NT) {
                 const float s = slab_sum(g2.c2b + (long long)row * (D + A) + cc, g2.nsplit, g2.stride_b);
-                if (cc < D) { sent_s[cc] = s + g2.b_sfc[cc]; if constexpr (SPLIT) sent_out[(long long)row * D + cc] = s + g2.b_sfc[cc]; }
+                if (cc < D) sent_s[cc] = s + g2.b_sfc[cc];
                 else sa_s[cc - D] = s;
             }
         }
@@ -559,7 +558,6 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
         }
         if (lane == 0) zsum[row] = zs;
     }
-    if constexpr (SPLIT) return;
     __syncthreads();
 
     // weighted sum.  Rows with alpha == 0 (zero padding) are skipped: no HBM read for them.  Four region rows are in
@@ -595,106 +593,6 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
         *reinterpret_cast<float4*>(att + (long long)row * D + d) = acc;
         if (att16) *reinterpret_cast<uint2*>(att16 + (long long)row * D + d) = bf16_bits4(acc);
     }
-}
-
-// att[row] = alpha_0 sentinel[row] + sum_r alpha_r regions[img, slot(row), r, :]  for every hypothesis of ONE image, one workgroup per
-// (image, chunk of 4 NT columns).  The region rows of a slot are loaded once and multiplied into the accumulators of every hypothesis
-// that sits on that slot; per hypothesis the arithmetic is k_attend's, expression for expression and in the same order (rows ascending,
-// chunks of CH rows, all-zero chunks skipped, zero-weight rows enter as exact zeros), so the result is bit-identical to the
-// one-workgroup-per-row kernel.                                                        (step :171)
-constexpr int WSUM_MAXH = 8;            // hypotheses per image (VSR_MAX_BEAM)
-template <int NT>
-__global__ __launch_bounds__(NT) void k_attend_wsum(const float* __restrict__ alpha, const float* __restrict__ sent,
-                                                    const float* __restrict__ regions, const int* __restrict__ ridx,
-                                                    const int* __restrict__ slot, int fixed_slot, int rpi, int B, int L, int R, int D,
-                                                    float* __restrict__ att, uint16_t* __restrict__ att16) {
-    extern __shared__ float sm[];
-    float* al_s = sm;                                   // rpi x (R + 1)
-    int* ri_s = reinterpret_cast<int*>(al_s + rpi * (R + 1));   // rpi x R: region row behind (hypothesis, entry)
-    int* sl_s = ri_s + rpi * R;                         // rpi
-    const int img = xcd_item(B);
-    if (img < 0) return;
-    const int tid = threadIdx.x;
-    const int d = (blockIdx.y * NT + tid) * 4;
-    for (int i = tid; i < rpi * (R + 1); i += NT) al_s[i] = alpha[(long long)img * rpi * (R + 1) + i];
-    for (int i = tid; i < rpi; i += NT) sl_s[i] = slot ? slot[img * rpi + i] : fixed_slot;
-    __syncthreads();
-    for (int i = tid; i < rpi * R; i += NT) {
-        const int h = i / R, r = i - h * R;
-        const long long sl = (long long)img * L + sl_s[h];
-        const int e = ridx ? ridx[sl * R + r] : (int)(sl * R + r);
-        ri_s[i] = e < 0 ? 0 : e;
-    }
-    __syncthreads();
-    if (d >= D) return;
-    float4 acc[WSUM_MAXH];
-#pragma unroll
-    for (int h = 0; h < WSUM_MAXH; ++h)
-        if (h < rpi) {
-            const float4 s = *reinterpret_cast<const float4*>(sent + (long long)(img * rpi + h) * D + d);
-            const float a0 = al_s[h * (R + 1)];
-            acc[h] = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
-        }
-    constexpr int CH = 18;
-    for (int h0 = 0; h0 < rpi; ++h0) {
-        // the group of hypotheses on h0's slot (h0 its first member)
-        bool first = true;
-        unsigned grp = 0;
-        for (int h = 0; h < rpi; ++h)
-            if (sl_s[h] == sl_s[h0]) { if (h < h0) first = false; grp |= 1u << h; }
-        if (!first) continue;
-        const int* ri = ri_s + h0 * R;
-        int r = 0;
-        for (; r + CH <= R; r += CH) {
-            bool any = false;
-            unsigned anyh = 0;
-#pragma unroll
-            for (int h = 0; h < WSUM_MAXH; ++h)
-                if (h < rpi && (grp >> h & 1)) {
-                    bool a = false;
-                    for (int q = 0; q < CH; ++q) a |= al_s[h * (R + 1) + r + 1 + q] != 0.f;
-                    if (a) anyh |= 1u << h;
-                    any |= a;
-                }
-            if (!any) continue;
-            float4 x[CH];
-#pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                bool need = false;
-                for (int h = 0; h < rpi; ++h) need |= (anyh >> h & 1) && al_s[h * (R + 1) + r + 1 + q] != 0.f;
-                x[q] = need ? *reinterpret_cast<const float4*>(regions + (long long)ri[r + q] * D + d) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int h = 0; h < WSUM_MAXH; ++h)
-                if (h < rpi && (anyh >> h & 1)) {
-#pragma unroll
-                    for (int q = 0; q < CH; ++q) {
-                        const float a = al_s[h * (R + 1) + r + 1 + q];
-                        const float4 xq = a != 0.f ? x[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-                        acc[h].x += a * xq.x; acc[h].y += a * xq.y; acc[h].z += a * xq.z; acc[h].w += a * xq.w;
-                    }
-                }
-        }
-        for (; r < R; ++r) {
-            bool need = false;
-            for (int h = 0; h < rpi; ++h) need |= (grp >> h & 1) && al_s[h * (R + 1) + r + 1] != 0.f;
-            if (!need) continue;
-            const float4 x = *reinterpret_cast<const float4*>(regions + (long long)ri[r] * D + d);
-#pragma unroll
-            for (int h = 0; h < WSUM_MAXH; ++h)
-                if (h < rpi && (grp >> h & 1)) {
-                    const float a = al_s[h * (R + 1) + r + 1];
-                    if (a != 0.f) { acc[h].x += a * x.x; acc[h].y += a * x.y; acc[h].z += a * x.z; acc[h].w += a * x.w; }
-                }
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < WSUM_MAXH; ++h)
-        if (h < rpi) {
-            const long long o = (long long)(img * rpi + h) * D + d;
-            *reinterpret_cast<float4*>(att + o) = acc[h];
-            if (att16) *reinterpret_cast<uint2*>(att16 + o) = bf16_bits4(acc[h]);
-        }
 }
 
 // LSTM2 pointwise                                                                     (step :176-177)

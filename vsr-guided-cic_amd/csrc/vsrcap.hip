@@ -65,7 +65,7 @@ struct Ctx {
     int nvalid = 0;
     float* st[2][4];   // h1, c1, h2, c2 double-buffered
     int *slot[2], *word[2], *gate[2], *parent;
-    float *s_t, *gpre, *g_t, *hA, *sa, *sent, *att, *zsum, *lg, *top_v, *alpha;
+    float *s_t, *gpre, *g_t, *hA, *sa, *sent, *att, *zsum, *lg, *top_v;
     float* ga_slabs;             // att_ga(g_t) partial sums: kept apart from `scratch`, the vocabulary GEMM overwrites that first
     int* top_i;
     float *seq[2], *mask[2];
@@ -158,6 +158,7 @@ struct vsr_handle {
     // shard of 12-13 images and its 65 beam rows, small eval batches) the 64-row tiles are mostly padding and the rows-16 kernel wins
     // (M = 13: 19.5 vs 13.2 TF/s over the four step GEMMs; beam-5 over a 13-image shard, M = 65: 3.48 vs 3.81 ms per call).
     int gemm_r16_max = 40;
+    int bf16_p_fp32 = 1;         // bf16 mode: the hoisted att_va(regions) GEMM of vsr_prepare*() stays fp32-equivalent (VSR_BF16_P_FP32=0: bf16 like the rest)
     int bf16_a16 = 1;            // bf16 mode: the decode step's producers write bf16 images of the GEMM A operands (VSR_BF16_A16=0: off)
     int gemm_aligned = 1;        // 128 x 256 kernels: k-aligned pieces (gemm_plan_aligned) when the tiles fit the CUs; VSR_GEMM_ALIGNED=0: stream-K always
     int gemm_aligned_min = 8;    // shortest piece, in 64-wide k-tiles (VSR_GEMM_ALIGNED_MIN)
@@ -228,7 +229,6 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     c.sent = b.take<float>(M * D);
     c.att = b.take<float>(M * D);
     c.zsum = b.take<float>(M);
-    c.alpha = b.take<float>(M * (c.R + 1));
     c.lg = b.take<float>(M * 2);
     c.ga_slabs = b.take<float>(M * A * 8);
     c.top_v = b.take<float>(M * KMAX);
@@ -278,12 +278,14 @@ struct GemmBuilder {
     int x3_tn = 2;       // f32x3 and bf16 kernels: workgroup tile 128 x 256 (2) or 128 x 128 (1)
     int x3s_mt = 0;      // weight-streaming f32x3 kernel (big = 34): 16-row tiles of A
     bool a16_all = false;   // bf16 kernel: every segment's A operand has a bf16 image (GemmSeg::A16)
+    bool keep_fp32 = false; // bf16 mode: this launch stays fp32-equivalent (f32x3 kernels): the hoisted att_va(regions) projection, whose
+                            // outputs are summed RAW over up to 36 rows into the shift logit (step :187) - bf16 rounding adds up coherently there
     bool stale_w = false;   // bf16 mode: a W operand exists only as a bf16 image but the launch does not qualify for the bf16 kernel
     // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
     int finish(const vsr_handle* h) {
         int maxM = 0;
         for (int i = 0; i < a.nprob; ++i) maxM = std::max(maxM, a.p[i].M);
-        if (h->bf16_on) {
+        if (h->bf16_on && !(keep_fp32 && h->bf16_p_fp32)) {
             // bf16 mode: every W operand of the launch must have a bf16 copy (and 16-byte-aligned 8-element chunks);
             // a launch that does not qualify runs on the fp32 kernel
             bool ok = true;
@@ -373,7 +375,7 @@ struct GemmBuilder {
                 return gemm_plan(a, slots, 4, 128, 256, H2_BK);
             }
         }
-        if (h->x3_on && h->gemm_tile == 0) {
+        if ((h->x3_on || (keep_fp32 && h->bf16_on && h->bf16_p_fp32)) && h->gemm_tile == 0) {
             // f32x3 (gemm_x3.h): 128 x 256 tiles from 193 rows up; 128 x 128 tiles for launches whose rows fit ONE m-tile (greedy
             // decoding, sampling, the per-step GEMMs of the training pass at batch 100, a shard of a strong-scaled decode): the
             // number of tiles is then the number of n-tiles, which 256-wide tiles would have to cut into ~10 k pieces each.
@@ -547,6 +549,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_GEMM_R16_MAX")) h->gemm_r16_max = atoi(e);
     if (const char* e = getenv("VSR_GEMM_ALIGNED")) h->gemm_aligned = atoi(e);
     if (const char* e = getenv("VSR_BF16_A16")) h->bf16_a16 = atoi(e);
+    if (const char* e = getenv("VSR_BF16_P_FP32")) h->bf16_p_fp32 = atoi(e);
     if (const char* e = getenv("VSR_GEMM_ALIGNED_MIN")) h->gemm_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS")) h->gemm_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_SMALL")) h->gemm_slots_small = std::max(1, atoi(e));
@@ -946,6 +949,7 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     if (indexed && back[1] != 0) return fail("%s: %d slot entries index outside the feature bank [-1, %d) or name an image outside [0, %d)", who, back[1], Rb, n_img);
     if (c.nvalid > 0) {
         GemmBuilder g;
+        g.keep_fp32 = true;
         GemmProb& p0 = g.prob(c.nvalid, A, c.scratch, A);
         GemmBuilder::seg(p0, regions, D, c.vlist, w.att_va_weight, D, D, nullptr, H2A_REGION);
         const int ns = g.finish(h);
@@ -1084,17 +1088,10 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         // k_gate2's work (g_t, hA, s_a, sentinel from the S2 slabs) is done by the attention kernel's row blocks themselves
         const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16};
         const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
-        // scores + softmax per row (alpha and the sentinel go to memory), then the weighted sums per IMAGE: hypotheses on the same slot
-        // share the region rows they read (one workgroup per row read them from L2 once per hypothesis: 200 MB per beam-5 launch)
-        float* alpha = io.alpha_out ? io.alpha_out : c.alpha;
-        if (D >= 2048) hipLaunchKernelGGL((k_attend<512, true>), dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, alpha, att16, c.sent);
-        else hipLaunchKernelGGL((k_attend<256, true>), dim3(cdiv(M, 8) * 8), dim3(256), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, alpha, att16, c.sent);
-        const int nimg = M / io.rpi;
-        const size_t wsm = (size_t)io.rpi * (2 * c.R + 2) * sizeof(float);
-        hipLaunchKernelGGL(k_attend_wsum<128>, dim3(cdiv(nimg, 8) * 8, cdiv(D, 512)), dim3(128), wsm, s, alpha, c.sent, c.regions, c.ridx, io.slot, io.fixed_slot,
-                           io.rpi, nimg, c.L, c.R, D, c.att, att16);
+        if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16);
+        else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16);
     }
     // ---- S5
     GateLogitArgs gate_args;
