@@ -133,7 +133,7 @@ struct Builder {
             for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
             return ns;
         }
-        if (tm == 5200) { bm = 128; bn = tn == 21 ? 128 : 256; a.exps = g_exps; }    // f16x2 wide kernel
+        if (tm == 5200) { bm = 128; bn = tn == 21 ? 128 : 256; a.exps = g_exps; }    // f16x2 wide kernel (H2_NW=3|4 stages of the weight ring)
         if (tm == 5300) {                                                            // f16x2 streaming kernel (<= 128 rows): "5300 <MT or 0 = by M>", H2S_NS=1|2 strips per wave
             a.exps = g_exps;
             const int mi = getenv("GEMM_PLAN_ALIGNED") ? atoi(getenv("GEMM_PLAN_ALIGNED")) : 8;
@@ -179,8 +179,13 @@ struct Builder {
             switch (mt) { H2S(1) H2S(2) H2S(3) H2S(4) H2S(5) H2S(6) H2S(7) default: if (ns2) hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 2>), g, dim3(H2S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 1>), g, dim3(H2S_THREADS), 0, st, a); break; }
 #undef H2S
         }
-        else if (tm == 5200 && tn == 21) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 1>), g, dim3(H2_THREADS), 0, st, a);
-        else if (tm == 5200) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2>), g, dim3(H2_THREADS), 0, st, a);
+        else if (tm == 5200) {
+            const int nw = getenv("H2_NW") ? atoi(getenv("H2_NW")) : 3;
+            if (tn == 21 && nw == 4) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 1, 4>), g, dim3(H2_THREADS), 0, st, a);
+            else if (tn == 21) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 1, 3>), g, dim3(H2_THREADS), 0, st, a);
+            else if (nw == 4) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2, 4>), g, dim3(H2_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2, 3>), g, dim3(H2_THREADS), 0, st, a);
+        }
         else if (is_x3(tm) && tn == 21) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), g, dim3(X3_THREADS), 0, st, a);
         else if (is_x3(tm)) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), g, dim3(X3_THREADS), 0, st, a);
         else if (tm == 1664 && tn == 21) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 1>), g, dim3(B16_THREADS), 0, st, a);

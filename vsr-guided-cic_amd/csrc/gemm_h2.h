@@ -20,7 +20,7 @@
 // core.  Only A (activations: a third of the wide tile's rows, a few rows of the streaming kernel's) is split in the kernel.
 //
 // Two kernels, both with the work decompositions of gemm_f32.h (stream-K ranges / k-aligned pieces, slab outputs):
-//   gemm_nt_h2_kernel<TM, TN>   16 waves (8 multiply, 8 move), 128 x 256 / 128 x 128 x 32 tiles: gemm_x3.h's structure
+//   gemm_nt_h2_kernel<TM, TN, NW>  16 waves (8 multiply, 8 move), 128 x 256 / 128 x 128 x 32 tiles, W by LDS-DMA into a ring of NW stages
 //   gemm_nt_h2s_kernel<MT, NS>  4 waves, <= 128 rows: W global -> register -> MFMA B operand, A staged through LDS: gemm_x3s.h's
 #pragma once
 #include <hip/hip_runtime.h>
@@ -123,6 +123,64 @@ __global__ __launch_bounds__(256) void k_f32_to_h2(const float* __restrict__ src
     *reinterpret_cast<uint4*>(dst + i + 4) = lo;
 }
 
+// the refresh after an optimizer step as TWO launches over all tensors instead of fifteen pairs (a training step pays for it: fifteen
+// k_absmax + fourteen k_f32_to_h2 launches were 0.36 ms of a 10 ms XE step).  Block -> tensor through a compare chain over static
+// indices (a run-time index into a by-value argument struct makes hipcc copy the struct to scratch).
+constexpr int H2_MT = 16;
+struct H2Multi {
+    const float* src[H2_MT];
+    long long n[H2_MT];         // elements (images: rounded up to 8)
+    long long dst_off[H2_MT];   // image offset in floats from the image base (conversion only)
+    int blk[H2_MT + 1];         // first block of tensor i; blk[nt] = grid size
+    int slot[H2_MT];            // bounds / exponent slot of tensor i
+    int nt;
+};
+__global__ __launch_bounds__(256) void k_absmax_multi(const H2Multi t, unsigned* __restrict__ bounds) {
+    const float* x = t.src[0];
+    long long n = t.n[0];
+    int b0 = 0, b1 = t.blk[1], slot = t.slot[0];
+#pragma unroll
+    for (int i = 1; i < H2_MT; ++i)
+        if (i < t.nt && (int)blockIdx.x >= t.blk[i]) { x = t.src[i]; n = t.n[i]; b0 = t.blk[i]; b1 = t.blk[i + 1]; slot = t.slot[i]; }
+    float m = 0.f;
+    const long long stride = (long long)(b1 - b0) * 256 * 4;
+    for (long long i = ((long long)(blockIdx.x - b0) * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 3 < n) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        } else {
+            for (long long j = i; j < n; ++j) m = fmaxf(m, fabsf(x[j]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (!(m == m)) m = __int_as_float(0x7f800000);
+        atomicMax(bounds + slot, __float_as_uint(m));
+    }
+}
+__global__ __launch_bounds__(256) void k_f32_to_h2_multi(const H2Multi t, uint32_t* __restrict__ img, const int* __restrict__ exps) {
+    const float* x = t.src[0];
+    long long n = t.n[0], off = t.dst_off[0];
+    int b0 = 0, slot = t.slot[0];
+#pragma unroll
+    for (int i = 1; i < H2_MT; ++i)
+        if (i < t.nt && (int)blockIdx.x >= t.blk[i]) { x = t.src[i]; n = t.n[i]; off = t.dst_off[i]; b0 = t.blk[i]; slot = t.slot[i]; }
+    const long long i = ((long long)(blockIdx.x - b0) * 256 + threadIdx.x) * 8;
+    if (i + 8 > n) return;
+    const float sc = h2_pow2(exps[slot]);
+    const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(x + i + 4);
+    uint4 hi, lo;
+    split_h2(a.x, a.y, sc, hi.x, lo.x); split_h2(a.z, a.w, sc, hi.y, lo.y);
+    split_h2(b.x, b.y, sc, hi.z, lo.z); split_h2(b.z, b.w, sc, hi.w, lo.w);
+    *reinterpret_cast<uint4*>(img + off + i) = hi;
+    *reinterpret_cast<uint4*>(img + off + i + 4) = lo;
+}
+
 // S of a problem: the common accumulator exponent = min over its segments of (weight exponent + exponent of A's bound)
 __device__ __forceinline__ int h2_prob_exp(const GemmArgs& args, const GemmProb& P) {
     int S = 1 << 20;
@@ -135,25 +193,49 @@ __device__ __forceinline__ int h2_prob_exp(const GemmArgs& args, const GemmProb&
     return S < -120 ? -120 : (S > 120 ? 120 : S);
 }
 
-constexpr size_t h2_lds_bytes(int TM, int TN) { return (size_t)2 * 2 * ((128 + 32 * TN * (8 / (4 / TM))) * H2_ROW + 32) * sizeof(uint16_t); }
-
 // ------------------------------------------------------------------------------------------------------------------------------
-// Wide kernel.  16 waves: waves 0-7 MULTIPLY (WM x WN waves, TM x TN 32x32 tiles each), waves 8-15 MOVE: asynchronous global loads two
-// k-tiles ahead; W chunks go to LDS as they are (ds_write_b128 into the hi or lo plane), A quads are scaled, split and stored
-// (two ds_write_b64).  LDS: two fp16 planes of (128 + BN) rows x 32 per buffer, chunk c of row r at c ^ ((r >> 2) & 3), double
-// buffered: 98 / 65 KB.  One barrier per k-tile; LDS-staged 16-byte epilogue stores scaled by 2^-S.
-template <int TM, int TN>
+// Wide kernel.  16 waves: waves 0-7 MULTIPLY (WM x WN waves, TM x TN 32x32 tiles each, three MFMAs per product), waves 8-15 MOVE.
+// WEIGHTS go global -> LDS directly (global_load_lds_dwordx4: no landing registers, no ds_write, nothing of W in the movers' dependent chain)
+// into a ring of NW stages, NW - 1 k-tiles ahead; only A (a third of the tile's bytes) passes through registers to be scaled and split.
+// The first version of this kernel staged W through registers like gemm_x3.h; its phase stamps (tools/h2_stamp.py on that version,
+// profiles/r04_d_h2_wide_plane_pad_and_phase_stamps.txt) showed a k-tile of ~3 300 cycles of which the multipliers work 765 and the movers'
+// chain - wait for the loads 930 | split + LDS stores 880 | issue 320 | barrier skew ~1 100 - is the rest; this version is 2 % faster end to
+// end (profiles/r04_g_h2_dma_ab.txt): the k loop is paced by the ~14.5 bytes per clock a CU takes in at the ~1.4 GHz it holds under this
+// load (48 KB per k-tile), not by latency - deeper rings (NW = 4) and more tiles in flight change nothing.
+//   * W stage: BN rows of 128 bytes = 8 chunks of 16 bytes, logical chunk c = 4 plane + k-group; position p of row R holds chunk
+//     p ^ ((R >> 1) & 7) (conflict-free for the ds_read_b128 lane groups at a 128-byte row stride).  One DMA instruction of a wave writes
+//     1 KB = 8 whole rows; lane l sends the image bytes of (row l >> 3, chunk (l & 7) ^ swizzle): every 128-byte line is read whole.
+//   * A: two fp16 planes of 128 rows x 64 bytes per buffer, chunk c of row r at c ^ ((r >> 2) & 3), double buffered, register-staged two
+//     k-tiles ahead (asynchronous loads with hand-counted waits: gemm_bf16.h's rules).
+//   * per k-tile j the movers: [issue W(j + NW - 1) into the stage the barrier has just freed, A(j + 2) into the register set stored last
+//     k-tile] [s_waitcnt vmcnt: A(j + 1) and every older request - W(j + 1) among them - have landed] [A(j + 1) -> split -> its buffer]
+//     [barrier].  K tails read a 16-byte block of zeros instead of the image.  The two instances of the period (register sets swapped)
+//     ALTERNATE STATICALLY: selected by a run-time test, the asynchronously loaded sets flow through a control-flow merge and hipcc
+//     moves them before they have landed (wrong sums and wild addresses: found the hard way, twice).
+// LDS: 32 KB of A + NW x 32 KB (BN = 256) / NW x 16 KB (BN = 128): 128 / 80 KB at NW = 3.  One barrier per k-tile; LDS-staged 16-byte
+// epilogue stores scaled by 2^-S.
+__device__ float g_h2_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// one LDS-DMA request (tools/gemm_dma_variant.h's): every lane sends its 16 bytes at gsrc to LDS byte address lds_dst + 16 * lane
+__device__ __forceinline__ void h2_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int TM, int TN, int NW = 3>
 __global__ __launch_bounds__(H2_THREADS)
 void gemm_nt_h2_kernel(const GemmArgs args) {
     constexpr int WM = 4 / TM, WN = 8 / WM;
     constexpr int BM = 128, BN = 32 * TN * WN, BK = H2_BK;
     static_assert(32 * TM * WM == BM, "tile shape");
-    // fp16 elements per plane: (BM + BN) rows of 64 bytes, + 64 bytes so that the lo plane starts 16 banks after the hi plane - the eight
-    // lanes that store one weight row (four k groups x {hi, lo}) then cover 32 different banks (without the pad the hi and lo chunk of a
-    // group collided two ways on every ds_write_b128: SQ_LDS_BANK_CONFLICT was 22 % of the LDS cycles, profiles/r04_b_h2_wide_sq_tcc_counters_M500.txt)
-    constexpr int PLANE = (BM + BN) * H2_ROW + 32;
-    constexpr int BUF = 2 * PLANE;                        // hi | lo
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];
+    constexpr int APLANE = BM * H2_ROW;                   // fp16 elements per A plane
+    constexpr int ABUF = 2 * APLANE;                      // hi | lo
+    constexpr int WSTAGE = BN * 64;                       // fp16 elements per W stage (BN rows x 128 bytes)
+    constexpr int L = 2 + BN / 64;                        // vector-memory requests per mover thread and k-tile: 2 A loads + BN / 64 DMAs
+    static_assert((2 * ABUF + NW * WSTAGE) * 2 <= 163840, "LDS");
+    __shared__ __attribute__((aligned(1024))) uint16_t smem[2 * ABUF + NW * WSTAGE];
+    uint16_t* const sW = smem + 2 * ABUF;
 
     const int G = args.G;
     const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
@@ -202,8 +284,10 @@ void gemm_nt_h2_kernel(const GemmArgs args) {
         return kt;
     };
 
-    constexpr int ST_LD = BN + 4;
-    static_assert(32 * ST_LD * 4 <= BUF * 2, "staging band must fit one k buffer");
+    // Epilogue of one tile piece, staged band by band in the W stage the multipliers have just finished with (32 rows x BN floats = one
+    // stage exactly).  Every request in flight is waited for first: the stage may be the target of nothing then, and stores share vmcnt.
+    constexpr int ST_LD = BN;
+    static_assert(32 * ST_LD * 4 <= WSTAGE * 2, "staging band must fit one W stage");
     f32x16 acc[TM][TN];
     auto flush = [&](auto MULT, float* stage) __attribute__((always_inline)) {
         const GemmProb& P = args.p[c_prob];
@@ -218,6 +302,7 @@ void gemm_nt_h2_kernel(const GemmArgs args) {
         const int n = n0 + c4;
         const int wm = wave / WN, wn = wave % WN;
         wait_loads<0>();
+        __syncthreads();                                   // ... for every wave's requests: nothing lands in `stage` from here on
 #pragma unroll
         for (int band = 0; band < BM / 32; ++band) {
             if (m0 + band * 32 >= P.M) break;
@@ -258,16 +343,20 @@ void gemm_nt_h2_kernel(const GemmArgs args) {
         }
         wait_loads<0>();
     };
-    int cur = 0, it = it0;
+    // k-tile number since it0 (its A buffer and A register set are j & 1, its W stage j % NW); end of a k-tile for BOTH kinds of waves.
+    // A flush drains every wave's request queue first and uses the stage just multiplied from: the tiles already prefetched stay where
+    // they are (the other stages, the A registers), only the queue is empty afterwards - the counted waits then return at once.
+    int j = 0, it = it0, ws = 0;                           // ws = j % NW
     auto end_of_ktile = [&](auto MULT) __attribute__((always_inline)) {
         ++it;
         const bool piece_done = --c_left == 0;
         __syncthreads();
         if (piece_done) {
-            flush(MULT, reinterpret_cast<float*>(smem + cur * BUF));
+            flush(MULT, reinterpret_cast<float*>(sW + ws * WSTAGE));
             if (it < it1) decode(it);
         }
-        cur ^= 1;
+        ++j;
+        ws = ws + 1 == NW ? 0 : ws + 1;
         return piece_done;
     };
 
@@ -275,170 +364,185 @@ void gemm_nt_h2_kernel(const GemmArgs args) {
 
     if (mover) {
         // ================================================================================================ movers
-        const int ptid = tid - 512;
-        const int lrow = ptid >> 3, j8 = ptid & 7, lk = j8 * 4;   // 8 lanes x 16 bytes cover a row's k-tile (one 128-byte line), 64 rows per pass
-        const int wplane = j8 & 1, wgrp = j8 >> 1;                // W image: chunk j8 of the line = plane (hi / lo) of k group j8 >> 1
-        constexpr int LA = BM / 64, LB = BN / 64;
-        f32x4_t ra[2][LA], rb[2][LB];
-        bool stla[2] = {false, false}, stlw[2] = {false, false};
-        float ssc[2] = {1.f, 1.f};                          // A scale of the tile in register set s
+        const int ptid = tid - 512, mw = wave - 8;
+        const int lrow = ptid >> 3, lk = (ptid & 7) * 4;   // A: 8 lanes x 16 bytes cover a row's k-tile, 64 rows per pass
+        constexpr int LA = BM / 64, LB = BN / 64;          // A loads / W DMAs per thread and k-tile
+        // W DMA: this lane's place in a 1 KB block = (row lane >> 3, position lane & 7) -> logical chunk -> image bytes
+        const int wr8 = lane >> 3;
+        const int wc = (lane & 7) ^ ((4 * (mw & 1) + (lane >> 4)) & 7);      // (R >> 1) & 7 for R = 8 (mw + 8 i) + (lane >> 3): the same for every i
+        const int wg8 = 8 * (wc & 3);                      // first k of the chunk's group inside the k-tile
+        const int wboff = (wc & 3) * 8 + (wc >> 2) * 4;    // its offset in the row's k-tile, in floats (32 bytes per group, the lo half 16 bytes in)
+        const unsigned lds_w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) void*)sW)
+                              + (unsigned)__builtin_amdgcn_readfirstlane(mw) * 1024u;
+        // TWO cursors walk the k-tiles of the range: W runs NW - 1 k-tiles ahead, A two.  (Scalars only; the pointers a role derives
+        // from its cursor are recomputed when the cursor enters a segment.)
+        struct Cursor {
+            int prob, tile, tile_left, seg, seg_left, k, K;
+            bool fresh;
+            __device__ __forceinline__ void open(const GemmArgs& a, int prob_, int tile_, int kt) {
+                prob = prob_; tile = tile_;
+                const GemmProb& P = a.p[prob_];
+                tile_left = P.ktiles - kt;
+                int sg = 0;
+                while (sg < P.nseg - 1 && kt >= (P.seg[sg].K + H2_BK - 1) / H2_BK) { kt -= (P.seg[sg].K + H2_BK - 1) / H2_BK; ++sg; }
+                seg = sg; K = P.seg[sg].K; k = kt * H2_BK; seg_left = (K + H2_BK - 1) / H2_BK - kt; fresh = true;
+            }
+            __device__ __forceinline__ void settle(const GemmArgs& a) {      // stand on a k-tile: cross segment / tile / problem boundaries
+                if (tile_left == 0) {
+                    if (tile + 1 < a.p[prob].tiles_m * a.p[prob].tiles_n) open(a, prob, tile + 1, 0);
+                    else open(a, prob + 1, 0, 0);
+                } else if (seg_left == 0) {
+                    ++seg; K = a.p[prob].seg[seg].K; k = 0; seg_left = (K + H2_BK - 1) / H2_BK; fresh = true;
+                }
+            }
+            __device__ __forceinline__ void next() { k += H2_BK; --seg_left; --tile_left; }
+        };
+        Cursor cw, ca;
         const float* pa[LA];
-        const float* pb[LB];
-        int l_prob = 0, l_tile = 0, l_tile_left = 0;
-        int l_seg = 0, l_seg_left = 0, l_k = 0, l_K = 0, l_S = 0;
-        float l_sc = 1.f;
-        auto open_segment = [&](int sg, int first_tile) __attribute__((always_inline)) {
-            const GemmProb& P = args.p[__builtin_amdgcn_readfirstlane(l_prob)];
-            const GemmSeg& S = P.seg[__builtin_amdgcn_readfirstlane(sg)];
-            const int m0 = (l_tile % P.tiles_m) * BM, n0 = (l_tile / P.tiles_m) * BN;
-            l_seg = sg;
-            l_K = S.K;
-            l_k = first_tile * BK;
-            l_seg_left = (S.K + BK - 1) / BK - first_tile;
-            l_sc = h2_pow2(l_S - args.exps[S.exp_idx & 0xffff]);      // <= the exponent of A's bound: no overflow
+        const float* pbW[LB];
+        float a_sc = 1.f;
+        auto issue_w = [&](int stage) __attribute__((always_inline)) {       // DMA the W cursor's k-tile into `stage`
+            cw.settle(args);
+            if (cw.fresh) {
+                const GemmProb& P = args.p[__builtin_amdgcn_readfirstlane(cw.prob)];
+                const GemmSeg& S = P.seg[__builtin_amdgcn_readfirstlane(cw.seg)];
+                const int n0 = (cw.tile / P.tiles_m) * BN;
+#pragma unroll
+                for (int i = 0; i < LB; ++i) {
+                    int n = n0 + 8 * (mw + 8 * i) + wr8;
+                    n = n < P.N ? n : P.N - 1;
+                    pbW[i] = S.W + (long long)n * S.ldw + wboff;       // the image has the fp32 matrix's byte geometry
+                }
+                cw.fresh = false;
+            }
+            const bool in = cw.k + wg8 < cw.K;             // K is a multiple of 8: a group is inside or outside as a whole
+            const unsigned base = lds_w0 + (unsigned)__builtin_amdgcn_readfirstlane(stage) * (unsigned)(WSTAGE * 2);
+#pragma unroll
+            for (int i = 0; i < LB; ++i) h2_glds16(in ? (const void*)(pbW[i] + cw.k) : (const void*)g_h2_zero16, base + (unsigned)(8 * i) * 1024u);
+            cw.next();
+        };
+        f32x4_t ra[2][LA];
+        bool stla[2] = {false, false};
+        float ssc[2] = {1.f, 1.f};
+        auto issue_a = [&](auto S_) __attribute__((always_inline)) {         // the A cursor's k-tile into register set S_
+            constexpr int s_ = decltype(S_)::value;
+            ca.settle(args);
+            if (ca.fresh) {
+                const GemmProb& P = args.p[__builtin_amdgcn_readfirstlane(ca.prob)];
+                const GemmSeg& S = P.seg[__builtin_amdgcn_readfirstlane(ca.seg)];
+                const int m0 = (ca.tile % P.tiles_m) * BM;
+#pragma unroll
+                for (int i = 0; i < LA; ++i) {
+                    int m = m0 + lrow + 64 * i;
+                    m = m < P.M ? m : P.M - 1;
+                    const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
+                    pa[i] = S.A + row * S.lda + lk;
+                }
+                a_sc = h2_pow2(exp_of_prob(ca.prob) - args.exps[S.exp_idx & 0xffff]);      // <= the exponent of A's bound: no overflow
+                ca.fresh = false;
+            }
+            const bool tail = !(ca.k + lk < ca.K);
+            const int ko = tail ? 0 : ca.k;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) async_load16(ra[s_][i], pa[i] + ko);
+            stla[s_] = tail; ssc[s_] = a_sc;
+            ca.next();
+        };
+        auto store_a = [&](auto S_, int b) __attribute__((always_inline)) {
+            constexpr int s_ = decltype(S_)::value;
+            uint16_t* buf = smem + b * ABUF;
+            const float sc = ssc[s_];
+#pragma unroll
+            for (int i = 0; i < LA; ++i) landed(ra[s_][i]);
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
-                int m = m0 + lrow + 64 * i;
-                m = m < P.M ? m : P.M - 1;
-                const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
-                pa[i] = S.A + row * S.lda + lk;
-            }
-#pragma unroll
-            for (int i = 0; i < LB; ++i) {
-                int n = n0 + lrow + 64 * i;
-                n = n < P.N ? n : P.N - 1;
-                pb[i] = S.W + (long long)n * S.ldw + lk;   // the image has the fp32 matrix's byte geometry
-            }
-        };
-        auto open_tile = [&](int prob, int tile, int kt) __attribute__((always_inline)) {
-            l_S = exp_of_prob(prob);
-            l_prob = prob;
-            l_tile = tile;
-            const GemmProb& P = args.p[prob];
-            l_tile_left = P.ktiles - kt;
-            int sg = 0;
-            while (sg < P.nseg - 1 && kt >= (P.seg[sg].K + BK - 1) / BK) { kt -= (P.seg[sg].K + BK - 1) / BK; ++sg; }
-            open_segment(sg, kt);
-        };
-        int koa = 0, kow = 0;
-        bool taila = false, tailw = false;
-        auto advance = [&]() __attribute__((always_inline)) {
-            if (l_tile_left == 0) {
-                if (l_tile + 1 < args.p[l_prob].tiles_m * args.p[l_prob].tiles_n) open_tile(l_prob, l_tile + 1, 0);
-                else open_tile(l_prob + 1, 0, 0);
-            } else if (l_seg_left == 0) {
-                open_segment(l_seg + 1, 0);
-            }
-            taila = !(l_k + lk < l_K);                     // K is a multiple of 8
-            tailw = !(l_k + 8 * wgrp < l_K);
-            koa = taila ? 0 : l_k;
-            kow = tailw ? 0 : l_k;
-            l_k += BK;
-            --l_seg_left;
-            --l_tile_left;
-        };
-        auto issue = [&](auto S) __attribute__((always_inline)) {
-            constexpr int s = decltype(S)::value;
-            advance();
-#pragma unroll
-            for (int i = 0; i < LA; ++i) async_load16(ra[s][i], pa[i] + koa);
-#pragma unroll
-            for (int i = 0; i < LB; ++i) async_load16(rb[s][i], pb[i] + kow);
-            stla[s] = taila; stlw[s] = tailw; ssc[s] = l_sc;
-        };
-        auto landed_set = [&](auto S, bool other_in_flight) __attribute__((always_inline)) {
-            constexpr int s = decltype(S)::value;
-            if (other_in_flight) wait_loads<LA + LB>(); else wait_loads<0>();
-#pragma unroll
-            for (int i = 0; i < LA; ++i) landed(ra[s][i]);
-#pragma unroll
-            for (int i = 0; i < LB; ++i) landed(rb[s][i]);
-        };
-        auto store_tile = [&](auto S, int b) __attribute__((always_inline)) {
-            constexpr int s = decltype(S)::value;
-            uint16_t* buf = smem + b * BUF;
-            const float sc = ssc[s];
-#pragma unroll
-            for (int i = 0; i < LA; ++i) {                  // A: this thread's 4 k's of row R -> 8 bytes per plane
                 const int R = lrow + 64 * i;
-                f32x4_t v = ra[s][i];
-                if (stla[s]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                f32x4_t v = ra[s_][i];
+                if (stla[s_]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 uint32_t h0, l0, h1, l1;
                 split_h2(v.x, v.y, sc, h0, l0);
                 split_h2(v.z, v.w, sc, h1, l1);
                 const int pos = R * H2_ROW + 8 * ((lk >> 3) ^ ((R >> 2) & 3)) + (lk & 4);
                 *reinterpret_cast<uint2*>(buf + pos) = make_uint2(h0, h1);
-                *reinterpret_cast<uint2*>(buf + PLANE + pos) = make_uint2(l0, l1);
-            }
-#pragma unroll
-            for (int i = 0; i < LB; ++i) {                  // W: a ready 16-byte fragment chunk of plane wplane
-                const int R = BM + lrow + 64 * i;
-                f32x4_t v = rb[s][i];
-                if (stlw[s]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4_t*>(buf + wplane * PLANE + R * H2_ROW + 8 * (wgrp ^ ((R >> 2) & 3))) = v;
+                *reinterpret_cast<uint2*>(buf + APLANE + pos) = make_uint2(l0, l1);
             }
         };
         using S0 = std::integral_constant<int, 0>;
         using S1 = std::integral_constant<int, 1>;
-        open_tile(c_prob, c_tile, kt0);
-        issue(S0{});
-        landed_set(S0{}, false);
-        store_tile(S0{}, 0);
-        if (it0 + 1 < it1) issue(S1{});
-        if (it0 + 2 < it1) issue(S0{});
-        __syncthreads();
-        auto step = [&](auto S) __attribute__((always_inline)) {
+        // prologue: W(0 .. NW - 2), A(0), A(1); A(0) -> buffer 0
+        cw.open(args, c_prob, c_tile, kt0);
+        ca = cw;
+        {
+            int st = 0;
+            for (int n = 0; n < NW - 1 && it0 + n < it1; ++n) { issue_w(st); ++st; }
+        }
+        issue_a(S0{});
+        if (it0 + 1 < it1) { issue_a(S1{}); wait_loads<LA>(); } else wait_loads<0>();      // A(0) and every W request before it
+        store_a(S0{}, 0);
+        __syncthreads();                                   // k-tile 0 is ready
+        // k-tile j: issue W(j + NW - 1) into the stage freed by the last barrier and A(j + 2) into the set stored last k-tile; wait for
+        // A(j + 1) - everything older, W(j + 1) included, has then landed; A(j + 1) -> split -> buffer (j + 1) & 1; barrier
+        auto period = [&](auto SN /* register set of k-tile j + 1 */, auto SP /* ... of k-tiles j and j + 2 */) __attribute__((always_inline)) {
+            const bool more_w = it + NW - 1 < it1, more_a = it + 2 < it1;
+            int st = ws + NW - 1;
+            st = st >= NW ? st - NW : st;
+            if (more_w) issue_w(st);
+            if (more_a) issue_a(SP);
             if (it + 1 < it1) {
-                landed_set(S, it + 2 < it1);
-                store_tile(S, cur ^ 1);
-                if (it + 3 < it1) issue(S);
+                if (more_w && more_a) wait_loads<LB + LA>();
+                else if (more_w) wait_loads<LB>();
+                else if (more_a) wait_loads<LA>();
+                else wait_loads<0>();
+                store_a(SN, (j + 1) & 1);
             }
             end_of_ktile(std::false_type{});
         };
+        // (static alternation: see the header comment)
         while (it < it1) {
-            step(S1{});
-            if (it < it1) step(S0{});
+            period(S1{}, S0{});                            // j even
+            if (it < it1) period(S0{}, S1{});              // j odd
         }
     } else {
         // ================================================================================================ multipliers
         const int wm = wave / WN, wn = wave % WN;
-        const int swz = (r >> 2) & 3;
+        const int swz = (r >> 2) & 3;                      // A planes: rows 32 t + r of every subtile share it
+        const int wsw = (r >> 1) & 7;                      // W stage: ((32 t + r) >> 1) & 7
         auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                    for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
         };
         zero_acc();
         __syncthreads();
         while (it < it1) {
-            const uint16_t* base = smem + cur * BUF;
-            const uint16_t* a_row = base + (wm * (32 * TM) + r) * H2_ROW;
-            const uint16_t* b_row = base + (BM + wn * (32 * TN) + r) * H2_ROW;
+            const uint16_t* a_row = smem + (j & 1) * ABUF + (wm * (32 * TM) + r) * H2_ROW;
+            const uint16_t* b_row = sW + ws * WSTAGE + (wn * (32 * TN) + r) * 64;
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
                 const int ch = 8 * ((2 * kk + hh) ^ swz);
+                const int wh = 8 * ((2 * kk + hh) ^ wsw), wl = 8 * ((4 + 2 * kk + hh) ^ wsw);
                 f16x8_t ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[i] = *reinterpret_cast<const f16x8_t*>(a_row + i * 32 * H2_ROW + ch);
-                    al[i] = *reinterpret_cast<const f16x8_t*>(a_row + PLANE + i * 32 * H2_ROW + ch);
+                    al[i] = *reinterpret_cast<const f16x8_t*>(a_row + APLANE + i * 32 * H2_ROW + ch);
                 }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bh[j] = *reinterpret_cast<const f16x8_t*>(b_row + j * 32 * H2_ROW + ch);
-                    bl[j] = *reinterpret_cast<const f16x8_t*>(b_row + PLANE + j * 32 * H2_ROW + ch);
+                for (int jj = 0; jj < TN; ++jj) {
+                    bh[jj] = *reinterpret_cast<const f16x8_t*>(b_row + jj * 32 * 64 + wh);
+                    bl[jj] = *reinterpret_cast<const f16x8_t*>(b_row + jj * 32 * 64 + wl);
                 }
-#define H2_TERM(X, Y)                                                                                   \
+#define H2D_TERM(X, Y)                                                                                  \
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[i], Y[j], acc[i][j], 0, 0, 0);
-                H2_TERM(al, bh)
-                H2_TERM(ah, bl)
-                H2_TERM(ah, bh)
-#undef H2_TERM
+        _Pragma("unroll") for (int jj = 0; jj < TN; ++jj)                                              \
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(X[i], Y[jj], acc[i][jj], 0, 0, 0);
+                H2D_TERM(al, bh)
+                H2D_TERM(ah, bl)
+                H2D_TERM(ah, bh)
+#undef H2D_TERM
             }
             if (end_of_ktile(std::true_type{})) zero_acc();
         }

@@ -107,7 +107,10 @@ struct vsr_handle {
     std::vector<H2Range> h2;
     int* h2_exps = nullptr;           // device: H2_NSLOT scale exponents ...
     unsigned* h2_bounds = nullptr;    // ... and the bounds they come from (bit patterns of non-negative floats)
-    int h2s_max = 128, h2s_slots = 512, h2s_min = 8, h2s_ns = 1;     // streaming kernel: launches of at most h2s_max rows (VSR_H2S_MAX / _SLOTS / _MIN / _NS)
+    // streaming kernel: launches of at most h2s_max rows (VSR_H2S_MAX / _SLOTS / _MIN / _NS).  Measured end to end in one run
+    // (profiles/r04_e_h2s_routing.txt): 80 - greedy (M = 100, then on the 128 x 128 tile) 660 k tokens/s against 632 k at 128, the 13-image shard
+    // (M = 65) 2.61 ms either way; 48 - greedy 668 k, the shard 2.75 ms
+    int h2s_max = 80, h2s_slots = 512, h2s_min = 8, h2s_ns = 1;
     int h2_aligned_min = 4;
     const H2Range* map_h2(const float* p) const {
         for (const H2Range& r : h2)
@@ -781,21 +784,41 @@ extern "C" int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes,
     unsigned* bounds = reinterpret_cast<unsigned*>(base + 128);
     int* idx = reinterpret_cast<int*>(base + 256);          // 3 x H2_NSLOT ints of index lists for k_h2_exps
     hipLaunchKernelGGL(k_h2_head_init, dim3(1), dim3(64), 0, s, exps, bounds, idx);
-    for (int i = 0; i < B16_NW; ++i)
-        hipLaunchKernelGGL(k_absmax, dim3(std::min<long long>(1024, cdiv((long long)n[i], 1024))), dim3(256), 0, s, p[i], (long long)n[i], bounds + i);
+    // bounds of the 14 matrices and of the embedding rows in one launch, the images in another (a training step refreshes them)
+    static_assert(B16_NW + 1 <= H2_MT, "multi-tensor table");
+    H2Multi mt;
+    memset(&mt, 0, sizeof(mt));
     const long long ne = (long long)d.vocab_size * d.input_encoding_size;
-    hipLaunchKernelGGL(k_absmax, dim3(std::min<long long>(1024, cdiv(ne, 1024))), dim3(256), 0, s, h->w.embed_weight, ne, bounds + H2A_EMBED);
+    int blocks = 0;
+    for (int i = 0; i <= B16_NW; ++i) {
+        mt.src[i] = i < B16_NW ? p[i] : h->w.embed_weight;
+        mt.n[i] = i < B16_NW ? (long long)n[i] : ne;
+        mt.slot[i] = i < B16_NW ? i : (int)H2A_EMBED;
+        mt.blk[i] = blocks;
+        blocks += (int)std::max<long long>(1, std::min<long long>(256, cdiv(mt.n[i], 8192)));
+    }
+    mt.blk[B16_NW + 1] = blocks;
+    mt.nt = B16_NW + 1;
+    hipLaunchKernelGGL(k_absmax_multi, dim3(blocks), dim3(256), 0, s, mt, bounds);
     // |sentinel| = |s_fc s_t + b| <= max_d (sum_j |W_dj| + |b_d|) since |s_t| < 1                                   (step :155)
     hipLaunchKernelGGL(k_row_l1_max, dim3(cdiv(d.det_feat_size, 4)), dim3(256), 0, s, h->w.s_fc_weight, h->w.s_fc_bias, d.det_feat_size, d.rnn_size, bounds + H2B_SENT);
     hipLaunchKernelGGL(k_h2_exps, dim3(1), dim3(64), 0, s, bounds, idx, idx + H2_NSLOT, idx + 2 * H2_NSLOT, (int)H2A_REGION, exps);   // slots 0 .. 15
     h->h2.clear();
     float* out = reinterpret_cast<float*>(base + H2_HEAD);
+    H2Multi mc;
+    memset(&mc, 0, sizeof(mc));
+    long long off = 0;
+    blocks = 0;
     for (int i = 0; i < B16_NW; ++i) {
         const size_t n8 = (n[i] + 7) & ~size_t(7);
-        hipLaunchKernelGGL(k_f32_to_h2, dim3(cdiv((long long)n8, 8 * 256)), dim3(256), 0, s, p[i], reinterpret_cast<uint32_t*>(out), (long long)n8, exps, i);
-        h->h2.push_back(H2Range{p[i], p[i] + n[i], out, i});
-        out += n8;
+        mc.src[i] = p[i]; mc.n[i] = (long long)n8; mc.dst_off[i] = off; mc.slot[i] = i; mc.blk[i] = blocks;
+        blocks += cdiv((long long)n8, 8 * 256);
+        h->h2.push_back(H2Range{p[i], p[i] + n[i], out + off, i});
+        off += (long long)n8;
     }
+    mc.blk[B16_NW] = blocks;
+    mc.nt = B16_NW;
+    hipLaunchKernelGGL(k_f32_to_h2_multi, dim3(blocks), dim3(256), 0, s, mc, reinterpret_cast<uint32_t*>(out), exps);
     LAUNCHCHK();
     h->h2_exps = exps; h->h2_bounds = bounds;
     if (!h->h2_on) { h->xproj = nullptr; invalidate_train_ctx(h->tc); }
@@ -1142,7 +1165,12 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         const long long stride = (long long)M * V;
         g.a.p[0].slab_stride = stride;
         for (int i = 1; i < g.a.nprob; ++i) g.a.p[i].slab_stride = (long long)M * 6 * H;
-        c.pre1_ns = ns; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
+        // ... and the LSTM1 / gate problems of the next step write (and k_lstm1 adds) only the slabs THEIR tiles can meet - all three get
+        // the largest of their counts, k_lstm1 takes one count for its six gate blocks
+        int ns_pre1 = 1;
+        for (int i = 1; i < g.a.nprob; ++i) ns_pre1 = std::max(ns_pre1, gemm_tight_slabs(g.a, i));
+        for (int i = 1; i < g.a.nprob; ++i) g.a.p[i].nslab = ns_pre1;
+        c.pre1_ns = g.a.nprob > 1 ? ns_pre1 : ns; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
         // the vocabulary tiles (K = H) are cut into fewer pieces than the LSTM1 tiles (K = 2 H) they share the launch with: k_vocab
         // adds only the slabs they wrote (60 -> 40 MB of logits per beam-5 step)
         const int ns_vocab = g.a.p[0].nslab = gemm_tight_slabs(g.a, 0);
