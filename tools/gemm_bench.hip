@@ -20,6 +20,7 @@
 #include "../vsr-guided-cic_amd/csrc/gemm_x3.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_x3s.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_h2.h"
+#include "../vsr-guided-cic_amd/csrc/gemm_h2a.h"
 
 using namespace vsr;
 
@@ -36,11 +37,13 @@ static int g_nslot = 0;
 constexpr int MAX_SLOTS = 4096;
 // f32x3 kernel (gemm_x3.h): variant "3300 <tm><tn>" with <tm><tn> = 22 (128 x 256 tile; also "1") or 21 (128 x 128)
 static bool is_x3(int tm) { return tm == 3300; }
-static bool is_h2(int tm) { return tm == 5200 || tm == 5300; }
+static bool g_h2a = false;                     // variant 5400: the all-DMA wide kernel (gemm_h2a.h): A operands are images too
+static bool is_h2(int tm) { return tm == 5200 || tm == 5300 || tm == 5400; }
 static void set_variant_globals(int tm) {
     g_bf16 = tm == 1664 || tm == 1665;
     g_a16 = tm == 1665;
     g_h2 = is_h2(tm);
+    g_h2a = tm == 5400;
 }
 
 static float* dev_rand(size_t n, unsigned seed) {
@@ -111,7 +114,7 @@ struct Builder {
     Builder(int slots_, int min_iters_, int tm_ = 1, int tn_ = 1) : slots(slots_), min_iters(min_iters_), tm(tm_), tn(tn_) { memset(&a, 0, sizeof(a)); }
     GemmProb& prob(int M, int N, float* C, int ldc) { GemmProb& p = a.p[a.nprob++]; p.M = M; p.N = N; p.C = C; p.ldc = ldc; return p; }
     static void seg(GemmProb& p, const float* A, int lda, const int* idx, const float* W, int ldw, int K) {
-        GemmSeg& s = p.seg[p.nseg++]; s.A = A; s.lda = lda; s.a_idx = idx; s.W = g_bf16 ? twin_of(W) : g_h2 ? h2_image_of(W) : W; s.ldw = ldw; s.K = K;
+        GemmSeg& s = p.seg[p.nseg++]; s.A = g_h2a ? h2_image_of(A) : A; s.lda = lda; s.a_idx = idx; s.W = g_bf16 ? twin_of(W) : g_h2 ? h2_image_of(W) : W; s.ldw = ldw; s.K = K;
         s.A16 = g_a16 ? reinterpret_cast<const uint16_t*>(twin_of(A)) : nullptr;
         s.exp_idx = 0;
         if (g_h2) s.exp_idx = slot_of(W) | (slot_of(A) << 16);
@@ -133,7 +136,7 @@ struct Builder {
             for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
             return ns;
         }
-        if (tm == 5200) { bm = 128; bn = tn == 21 ? 128 : 256; a.exps = g_exps; }    // f16x2 wide kernel (H2_NW=3|4 stages of the weight ring)
+        if (tm == 5200 || tm == 5400) { bm = 128; bn = tn == 21 ? 128 : 256; a.exps = g_exps; }    // f16x2 wide kernel (H2_NW=3|4 stages of the weight ring)
         if (tm == 5300) {                                                            // f16x2 streaming kernel (<= 128 rows): "5300 <MT or 0 = by M>", H2S_NS=1|2 strips per wave
             a.exps = g_exps;
             const int mi = getenv("GEMM_PLAN_ALIGNED") ? atoi(getenv("GEMM_PLAN_ALIGNED")) : 8;
@@ -146,7 +149,7 @@ struct Builder {
         if (tm == 1664 || tm == 1665) { bm = 128; bn = tn == 21 ? 128 : 256; }       // bf16 throughput kernel (bf16 W twins; 1665: bf16 A images too); tn 21: 128 x 128 tile
         int ns = 0;
         const bool b16 = tm == 1664 || tm == 1665;
-        if ((b16 || is_x3(tm) || tm == 5200) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, b16 ? B16_BK : GEMM_BK);
+        if ((b16 || is_x3(tm) || tm == 5200 || tm == 5400) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, b16 ? B16_BK : GEMM_BK);
         if (!ns) ns = gemm_plan(a, slots, min_iters, bm, bn, b16 ? B16_BK : GEMM_BK);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
         return ns;
@@ -178,6 +181,10 @@ struct Builder {
 #define H2S(MT_) case MT_: if (ns2) hipLaunchKernelGGL((gemm_nt_h2s_kernel<MT_, 2>), g, dim3(H2S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_h2s_kernel<MT_, 1>), g, dim3(H2S_THREADS), 0, st, a); break;
             switch (mt) { H2S(1) H2S(2) H2S(3) H2S(4) H2S(5) H2S(6) H2S(7) default: if (ns2) hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 2>), g, dim3(H2S_THREADS), 0, st, a); else hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 1>), g, dim3(H2S_THREADS), 0, st, a); break; }
 #undef H2S
+        }
+        else if (tm == 5400) {
+            if (tn == 21) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1, 3>), g, dim3(H2_THREADS), 0, st, a);
+            else hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 2, 3>), g, dim3(H2_THREADS), 0, st, a);
         }
         else if (tm == 5200) {
             const int nw = getenv("H2_NW") ? atoi(getenv("H2_NW")) : 3;
@@ -334,7 +341,7 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
                 const int q = wide ? 8 : 4;
                 const int K = q * rnd(1, rnd(0, 3) ? 520 / q : 1600 / q);
                 const int rowsA = rnd(0, 1) ? h.M : h.M + rnd(1, 50);
-                const int lda = g_a16 ? K + 8 * rnd(0, 2) : K + 4 * rnd(0, 3), woff = q * rnd(0, 4), ldw = woff + K + q * rnd(0, 5);
+                const int lda = (g_a16 || g_h2a) ? K + 8 * rnd(0, 2) : K + 4 * rnd(0, 3), woff = q * rnd(0, 4), ldw = woff + K + q * rnd(0, 5);
                 float* A = dev_rand((size_t)rowsA * lda, seed * 131 + cs * 17 + p * 5 + sg); to_free.push_back(A);
                 float* W = dev_rand((size_t)h.N * ldw + 64, seed * 137 + cs * 19 + p * 7 + sg); to_free.push_back(W);
                 std::vector<int> idx;
@@ -465,7 +472,7 @@ int main(int argc, char** argv) {
 
     // ---- correctness on a ragged problem: gather index, 3 segments with K tails, split-K, column window
     {
-        const int m = 77, n = 150, k1 = 72, k2 = 40, k3 = 100, ldw = 264, nrowsA = 200;     // (ldw a multiple of 8: the f16x2 image groups)
+        const int m = 77, n = 150, k1 = 72, k2 = 40, k3 = g_h2a ? 104 : 100, ldw = 264, nrowsA = 200;     // (ldw a multiple of 8: the f16x2 image groups)
         float* A1 = dev_rand((size_t)nrowsA * k1, 1); float* A2 = dev_rand((size_t)nrowsA * k2, 2); float* A3 = dev_rand((size_t)m * k3, 3);
         float* W = dev_rand((size_t)n * ldw, 4);
         std::vector<int> hidx(m); for (int i = 0; i < m; ++i) hidx[i] = (i * 37 + 11) % nrowsA;

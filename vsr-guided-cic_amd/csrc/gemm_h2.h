@@ -181,13 +181,17 @@ __global__ __launch_bounds__(256) void k_f32_to_h2_multi(const H2Multi t, uint32
     *reinterpret_cast<uint4*>(img + off + i + 4) = lo;
 }
 
+constexpr int H2_DYN0 = 256;        // first "dynamic" slot of the exponent table (see h2_prob_exp)
 // S of a problem: the common accumulator exponent = min over its segments of (weight exponent + exponent of A's bound)
 __device__ __forceinline__ int h2_prob_exp(const GemmArgs& args, const GemmProb& P) {
     int S = 1 << 20;
 #pragma unroll
     for (int sg = 0; sg < 3; ++sg)
         if (sg < P.nseg) {
-            const int e = args.exps[P.seg[sg].exp_idx & 0xffff] + args.exps[P.seg[sg].exp_idx >> 16];
+            // A slots from H2_DYN0 up hold the BOUND itself (bit pattern of a non-negative float, folded in by the kernel that wrote the
+            // operand - the gradient operands of the training pass, whose range is only known once they exist)
+            const int ia = P.seg[sg].exp_idx >> 16, va = args.exps[ia];
+            const int e = args.exps[P.seg[sg].exp_idx & 0xffff] + (ia >= H2_DYN0 ? h2_exp_of(__int_as_float(va)) : va);
             S = e < S ? e : S;
         }
     return S < -120 ? -120 : (S > 120 ? 120 : S);

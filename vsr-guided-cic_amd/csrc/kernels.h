@@ -41,6 +41,32 @@ __device__ __forceinline__ uint2 bf16_bits4(float4 v) {
     return make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, b2)), __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, b2)));
 }
 
+// Images of A operands for the GEMM kernels that take them (GemmSeg::A16), written by the producers next to the fp32 values.
+// isc == 0: bf16, 2 bytes per element (bf16 mode).  isc > 0: the f16x2 flavour's fp16 pairs of x * isc in the fp32 matrix's byte geometry
+// (gemm_h2a.h: both operands go global -> LDS by DMA, nothing is converted in the GEMM): elements [8 g, 8 g + 8) -> [hi x 8 | lo x 8],
+// `img` then addresses 2-byte units of a 4-byte-per-element buffer.  idx = row * ld + column with ld a multiple of 8.
+__device__ __forceinline__ void img_store(uint16_t* __restrict__ img, long long idx, float v, float isc) {
+    if (isc == 0.f) { img[idx] = bf16_bits(v); return; }
+    const float x = v * isc;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    uint16_t* g = img + ((idx >> 3) << 4) + (idx & 7);
+    g[0] = __builtin_bit_cast(uint16_t, hi);
+    g[8] = __builtin_bit_cast(uint16_t, lo);
+}
+__device__ __forceinline__ void img_store4(uint16_t* __restrict__ img, long long idx /* a multiple of 4 */, float4 v, float isc) {
+    if (isc == 0.f) { *reinterpret_cast<uint2*>(img + idx) = bf16_bits4(v); return; }
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 x = {v.x * isc, v.y * isc, v.z * isc, v.w * isc};
+    const h4 hi = __builtin_convertvector(x, h4);
+    const f4 rr = x - __builtin_convertvector(hi, f4);
+    const h4 lo = __builtin_convertvector(rr, h4);
+    uint16_t* g = img + ((idx >> 3) << 4) + (idx & 7);
+    *reinterpret_cast<uint2*>(g) = __builtin_bit_cast(uint2, hi);
+    *reinterpret_cast<uint2*>(g + 8) = __builtin_bit_cast(uint2, lo);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -297,7 +323,7 @@ __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long str
                         int rpi, const int* __restrict__ parent, const float* __restrict__ c1_old, int M, int H,
                         float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre,
                         const float* __restrict__ xproj, const int* __restrict__ word, int nblk, int pre_by_parent,
-                        uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16 /* optional bf16 images (bf16 GEMM mode) */) {
+                        uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16 /* optional images (img_store) */, float isc = 0.f) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
@@ -322,7 +348,7 @@ __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long str
     c1n[i] = c;
     s_t[i] = stv;
     gpre[i] = q[5];
-    if (h1n16) { h1n16[i] = bf16_bits(h1v); s_t16[i] = bf16_bits(stv); }
+    if (h1n16) { img_store(h1n16, i, h1v, isc); img_store(s_t16, i, stv, isc); }
 }
 
 // reduce the slabs of h1 -> [W1_hg | att_ha] and s_t -> [s_fc | att_sa]; finish the shift-gate vector
@@ -367,7 +393,8 @@ struct Gate2Args {
     const float* c2a; const float* c2b; int nsplit; long long stride_a, stride_b;
     const float* gpre; const float* c1n; const float* b_sfc; int H;
     float* g_t; float* hA_out;
-    uint16_t* g_t16 = nullptr;      // optional bf16 image of g_t (bf16 GEMM mode)
+    uint16_t* g_t16 = nullptr;      // optional image of g_t (img_store)
+    float isc = 0.f;                // ... its kind / scale; att16 of k_attend: bf16 when 0, else fp16 pairs scaled by 2^*att_exp
 };
 
 // (Round 4 measured the split the round-3 review asked for - this kernel stopping behind the softmax, a second kernel forming the weighted
@@ -383,7 +410,8 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                                                 int R, int A, int D, const float* __restrict__ w_a,
                                                 const float* __restrict__ w_s, float* __restrict__ att,
                                                 float* __restrict__ zsum, float* __restrict__ alpha_out,
-                                                uint16_t* __restrict__ att16 = nullptr /* optional bf16 image of att */) {
+                                                uint16_t* __restrict__ att16 = nullptr /* optional image of att */,
+                                                const int* __restrict__ att_exp = nullptr) {
     extern __shared__ float sm[];
     float* hA_s = sm;             // A
     float* sa_s = hA_s + A;       // A   (fused gate2 only)
@@ -425,7 +453,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                     o.x = sigmoidf_(gp.x + s.x) * tanhf(cn.x); o.y = sigmoidf_(gp.y + s.y) * tanhf(cn.y);
                     o.z = sigmoidf_(gp.z + s.z) * tanhf(cn.z); o.w = sigmoidf_(gp.w + s.w) * tanhf(cn.w);
                     *reinterpret_cast<float4*>(g2.g_t + (long long)row * H + c) = o;
-                    if (g2.g_t16) *reinterpret_cast<uint2*>(g2.g_t16 + (long long)row * H + c) = bf16_bits4(o);
+                    if (g2.g_t16) img_store4(g2.g_t16, (long long)row * H + c, o, g2.isc);
                 } else {
                     *reinterpret_cast<float4*>(hA_s + (c - H)) = s;
                     *reinterpret_cast<float4*>(g2.hA_out + (long long)row * A + (c - H)) = s;
@@ -454,7 +482,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                 if (c < H) {
                     const float gv = sigmoidf_(g2.gpre[(long long)row * H + c] + s) * tanhf(g2.c1n[(long long)row * H + c]);
                     g2.g_t[(long long)row * H + c] = gv;
-                    if (g2.g_t16) g2.g_t16[(long long)row * H + c] = bf16_bits(gv);
+                    if (g2.g_t16) img_store(g2.g_t16, (long long)row * H + c, gv, g2.isc);
                 } else {
                     hA_s[c - H] = s;
                     g2.hA_out[(long long)row * A + (c - H)] = s;
@@ -563,6 +591,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     // weighted sum.  Rows with alpha == 0 (zero padding) are skipped: no HBM read for them.  Four region rows are in
     // flight per thread (independent loads) so that the 8 KB rows stream instead of paying one L2/HBM latency each.
     const float a0 = z_s[0];
+    const float att_isc = att_exp ? __int_as_float((127 + *att_exp) << 23) : 0.f;      // 2^exponent of the attended vector's bound class
     for (int d = tid * 4; d < D; d += 4 * NT) {
         const float4 s = *reinterpret_cast<const float4*>(srow + d);
         float4 acc = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
@@ -591,7 +620,7 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
             }
         }
         *reinterpret_cast<float4*>(att + (long long)row * D + d) = acc;
-        if (att16) *reinterpret_cast<uint2*>(att16 + (long long)row * D + d) = bf16_bits4(acc);
+        if (att16) img_store4(att16, (long long)row * D + d, acc, att_isc);
     }
 }
 
@@ -599,7 +628,8 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
 __global__ void k_lstm2(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ b_ih,
                         const float* __restrict__ b_hh, const float* __restrict__ vproj2, int rpi,
                         const int* __restrict__ parent, const float* __restrict__ c2_old, int M, int H,
-                        float* __restrict__ h2n, float* __restrict__ c2n, uint16_t* __restrict__ h2n16 = nullptr /* optional bf16 image */) {
+                        float* __restrict__ h2n, float* __restrict__ c2n, uint16_t* __restrict__ h2n16 = nullptr /* optional image (img_store) */,
+                        float isc = 0.f) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
@@ -617,7 +647,7 @@ __global__ void k_lstm2(const float* __restrict__ pre, int nsplit, long long str
     const float h2v = sigmoidf_(q[3]) * tanhf(c);
     h2n[i] = h2v;
     c2n[i] = c;
-    if (h2n16) h2n16[i] = bf16_bits(h2v);
+    if (h2n16) img_store(h2n16, i, h2v, isc);
 }
 
 // shift-gate log-probabilities: z_g = w_g . tanh(att_ga g_t + hA); gate = log_softmax([z_g, zsum])   (:184-188)

@@ -39,6 +39,13 @@ struct TrainCtx {
     // weight-gradient products) has a bf16 twin the transposing kernels write instead of the fp32 buffer
     struct Twin { const float* f; size_t n; uint16_t* b; };
     std::vector<Twin> twins;
+    // f16x2 flavour: the same operands have fp16-pair images (gemm_h2.h) in h2img, made from the fp32 buffers by ONE multi-tensor
+    // launch per group (transposed weights / transposed activations); slot = exponent slot of the values (the weight's own, or the
+    // class of the activation)
+    struct Img { const float* f; size_t n; size_t off; int slot; };
+    std::vector<Img> imgs;
+    size_t n_wT_imgs = 0;        // the first entries of imgs: the transposed weights
+    float* h2img = nullptr;
 };
 
 static inline size_t up4(size_t x) { return (x + 7) & ~size_t(7); }   // K paddings: multiples of 8 (16-byte bf16 chunks; fp32 needs 4)
@@ -92,6 +99,26 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.tY_dpre1sum = b.take<float>(6 * H * Bp); t.tY_dpre2sum = b.take<float>(4 * H * Bp); t.tY_dP = b.take<float>(A * RLp);
     twin(t.tX_h2prev, H * TBp); twin(t.tX_x, E * TBp); twin(t.tX_h1prev, H * TBp); twin(t.tX_h1, H * TBp); twin(t.tX_att, D * TBp);
     twin(t.tX_st, H * TBp); twin(t.tX_gt, H * TBp); twin(t.tX_h2, H * TBp); twin(t.tX_vbar, D * Bp); twin(t.tX_reg, D * RLp);
+    t.imgs.clear(); t.n_wT_imgs = 0; t.h2img = nullptr;
+    if (h->h2_on && !h->bf16_on) {
+        size_t off = 0;
+        auto img = [&](const float* f, size_t n, int slot) { t.imgs.push_back(TrainCtx::Img{f, n, off, slot}); off += up4(n); };
+        // (slots 0..13: field order of b16_weight_list - the transposed matrix has the bound of the matrix)
+        const vsr_weights& w = h->w;
+        img(t.wT_ih1, in1 * 4 * H, h->h2_slot_of(w.lstm1_weight_ih)); img(t.wT_is, in1 * H, h->h2_slot_of(w.W1_is_weight));
+        img(t.wT_ig, in1 * H, h->h2_slot_of(w.W1_ig_weight)); img(t.wT_hh1, H * 4 * H, h->h2_slot_of(w.lstm1_weight_hh));
+        img(t.wT_hs, H * H, h->h2_slot_of(w.W1_hs_weight)); img(t.wT_ih2, in2 * 4 * H, h->h2_slot_of(w.lstm2_weight_ih));
+        img(t.wT_hh2, H * 4 * H, h->h2_slot_of(w.lstm2_weight_hh)); img(t.wT_hg, H * H, h->h2_slot_of(w.W1_hg_weight));
+        img(t.wT_ha, H * A, h->h2_slot_of(w.att_ha_weight)); img(t.wT_sfc, H * D, h->h2_slot_of(w.s_fc_weight));
+        img(t.wT_sa, H * A, h->h2_slot_of(w.att_sa_weight)); img(t.wT_ga, H * A, h->h2_slot_of(w.att_ga_weight));
+        img(t.wT_out, H * up4(V), h->h2_slot_of(w.out_fc_weight));
+        t.n_wT_imgs = t.imgs.size();
+        img(t.tX_h2prev, H * TBp, H2A_UNIT); img(t.tX_x, E * TBp, H2A_EMBED); img(t.tX_h1prev, H * TBp, H2A_UNIT); img(t.tX_h1, H * TBp, H2A_UNIT);
+        img(t.tX_att, D * TBp, H2A_ATT); img(t.tX_st, H * TBp, H2A_UNIT); img(t.tX_gt, H * TBp, H2A_UNIT); img(t.tX_h2, H * TBp, H2A_UNIT);
+        img(t.tX_vbar, D * Bp, H2A_DET); img(t.tX_reg, D * RLp, H2A_REGION);
+        b.off = (b.off + 255) & ~size_t(255);
+        t.h2img = b.take<float>(off);
+    }
     // GEMM slab scratch: 8 slabs of the largest product of the training path
     size_t big = std::max({4 * H * in1, V * H, 4 * H * in2, A * D, TB * H, TB * E, D * H, B * (in2 + 2 * H), H * in1, TB * V, TB * 6 * H});
     t.scratch_floats = big * 8;
@@ -99,13 +126,44 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     return (b.off + 255) & ~size_t(255);
 }
 
-struct SegSpec { const float* A; int lda; const float* W; int ldw; int K; };
+struct SegSpec { const float* A; int lda; const float* W; int ldw; int K; int a_cls = H2A_NONE; };
+
+// f16x2 flavour: fp16-pair images of imgs[i0, i1) from their fp32 buffers, one launch (n_override: elements of the LAST tensor actually in use)
+static void h2_images(vsr_handle* h, TrainCtx& t, hipStream_t s, size_t i0, size_t i1, long long n_last = -1) {
+    while (i0 < i1) {
+        H2Multi mc;
+        memset(&mc, 0, sizeof(mc));
+        int blocks = 0, k = 0;
+        for (; i0 < i1 && k < H2_MT; ++i0, ++k) {
+            const TrainCtx::Img& im = t.imgs[i0];
+            const long long n = (i0 + 1 == i1 && n_last >= 0) ? n_last : (long long)im.n;
+            mc.src[k] = im.f; mc.n[k] = (n + 7) & ~7LL; mc.dst_off[k] = (long long)im.off; mc.slot[k] = im.slot; mc.blk[k] = blocks;
+            blocks += (int)cdiv(mc.n[k], 8 * 256);
+        }
+        mc.blk[k] = blocks; mc.nt = k;
+        if (blocks > 0) hipLaunchKernelGGL(k_f32_to_h2_multi, dim3(blocks), dim3(256), 0, s, mc, reinterpret_cast<uint32_t*>(t.h2img), h->h2_exps);
+    }
+}
+// whole-pass bounds from the per-step ones (block 63: max over the steps; block 62 slots 2, 3: the sums over t of dpre1 / dpre2 rows)
+__global__ void k_h2_dyn_fold(int* __restrict__ dyn, int T) {
+    const int j = threadIdx.x;
+    if (j >= 8) return;
+    int m = 0;
+    for (int tt = 0; tt < T; ++tt) m = max(m, dyn[tt * 8 + j]);
+    dyn[63 * 8 + j] = m;
+    if (j == 0) dyn[62 * 8 + 3] = __float_as_int(__int_as_float(m) * (float)T);
+    if (j == 6) {
+        int m2 = 0;
+        for (int tt = 0; tt < T; ++tt) m2 = max(m2, dyn[tt * 8 + 2]);
+        dyn[62 * 8 + 2] = __float_as_int(fmaxf(__int_as_float(m), __int_as_float(m2)) * (float)T);
+    }
+}
 
 // one problem, several K segments -> dst window (ldd), through the slab scratch
 static int gemm_to(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, const SegSpec* segs, int nseg, float* dst, long long ldd) {
     GemmBuilder g;
     GemmProb& p = g.prob(M, N, t.scratch, N);
-    for (int i = 0; i < nseg; ++i) GemmBuilder::seg(p, segs[i].A, segs[i].lda, nullptr, segs[i].W, segs[i].ldw, segs[i].K);
+    for (int i = 0; i < nseg; ++i) GemmBuilder::seg(p, segs[i].A, segs[i].lda, nullptr, segs[i].W, segs[i].ldw, segs[i].K, nullptr, segs[i].a_cls);
     const int ns = g.finish(h);
     const long long stride = (long long)M * N;
     if (ns == 1) {                          // every tile is produced by one workgroup: it writes the destination window itself
@@ -120,8 +178,8 @@ static int gemm_to(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, cons
     return 0;
 }
 static int gemm_to1(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, int K, const float* A, int lda, const float* W, int ldw,
-                    float* dst, long long ldd) {
-    SegSpec sg{A, lda, W, ldw, K};
+                    float* dst, long long ldd, int a_cls = H2A_NONE) {
+    SegSpec sg{A, lda, W, ldw, K, a_cls};
     return gemm_to(h, t, s, M, N, &sg, 1, dst, ldd);
 }
 // deterministic two-stage column sum through the (idle) slab scratch
@@ -171,6 +229,8 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     if (need > train_ws_bytes) return fail("vsr_train_forward: training workspace too small (%zu < %zu)", train_ws_bytes, need);
     h->b16.resize(h->b16_weights);                         // (re)register the bf16 twins of this workspace
     for (const TrainCtx::Twin& tw : t.twins) h->b16.push_back(Bf16Range{tw.f, tw.f + tw.n, tw.b});
+    h->h2t.clear();                                        // ... and the fp16-pair images
+    for (const TrainCtx::Img& im : t.imgs) h->h2t.push_back(H2Range{im.f, im.f + im.n, t.h2img + im.off, im.slot});
     const int TB = T * B;
     const size_t BH = (size_t)B * H;
     HIPCHK(hipMemsetAsync(t.h1s, 0, BH * sizeof(float), s));
@@ -313,7 +373,7 @@ extern "C" int64_t vsr_train_generation(const vsr_handle* h) { return (h && h->t
 
 // dlogits in (t, b) row order from the (B, T, V) tensors
 __global__ __launch_bounds__(256) void k_dlogits_tb(const float* __restrict__ logp, const float* __restrict__ dlogp, int B, int T, int V,
-                                                    int Vp, float* __restrict__ dlogits) {
+                                                    int Vp, float* __restrict__ dlogits, int* bm) {
     __shared__ float red[4];
     const int tt = blockIdx.x / B, b = blockIdx.x % B;
     const long long src = ((long long)b * T + tt) * V, dst = (long long)blockIdx.x * Vp;
@@ -324,7 +384,13 @@ __global__ __launch_bounds__(256) void k_dlogits_tb(const float* __restrict__ lo
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-    for (int v = tid; v < Vp; v += 256) dlogits[dst + v] = v < V ? dlogp[src + v] - expf(logp[src + v]) * tot : 0.f;
+    float mx = 0.f;
+    for (int v = tid; v < Vp; v += 256) {
+        const float o = v < V ? dlogp[src + v] - expf(logp[src + v]) * tot : 0.f;
+        dlogits[dst + v] = o;
+        mx = fmaxf(mx, fabsf(o));
+    }
+    if (bm) block_absmax_to(mx, bm);
 }
 
 __global__ void k_sum_over_t(const float* __restrict__ X, int T, long long per_t, float* __restrict__ out) {
@@ -376,6 +442,18 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         if (uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(t.wT_out)) : nullptr) HIPCHK(hipMemsetAsync(tw, 0, (size_t)H * Vp * sizeof(uint16_t), s));
     }
     transpose(h, s, w.out_fc_weight, H, V, H, t.wT_out, Vp);
+    // f16x2 flavour: images of the transposed weights; the A operands of the backward GEMMs are gradients: their producers fold max |x|
+    // into "dynamic" slots of the exponent table (block tt of 8 slots for step tt, blocks 62 / 63 for the whole-pass operands)
+    const bool h2b = h->h2_on && !h->bf16_on && t.h2img && T <= 62;
+    int* dyn = h2b ? h->h2_exps + H2_DYN0 : nullptr;
+    enum { DY_dpre2, DY_dga, DY_dq, DY_dhA, DY_dsent, DY_dsa, DY_dpre1 };               // per-step block
+    enum { DW_dlogits = 62 * 8, DW_dP, DW_dpre1sum, DW_dpre2sum, DW_step = 63 * 8 };      // whole-pass slots (DW_step + DY_x: max over the steps)
+    auto dslot = [&](int i) { return h2b ? H2_DYN0 + i : (int)H2A_NONE; };
+    auto dptr = [&](int i) { return h2b ? dyn + i : (int*)nullptr; };
+    if (h2b) {
+        HIPCHK(hipMemsetAsync(dyn, 0, H2_NDYN * sizeof(int), s));
+        h2_images(h, t, s, 0, t.n_wT_imgs);
+    }
     HIPCHK(hipMemsetAsync(t.dP, 0, (size_t)RL * A * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dh1_c, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dh2_c, 0, BH * sizeof(float), s));
@@ -385,8 +463,8 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     // (the K padding of the transposed operands - TBp, Bp, NVp columns - is zero-filled by the transposing kernel itself)
 
     // ---- phase 0: dlogits (t,b) and the vocabulary part of dh2 for every step
-    hipLaunchKernelGGL(k_dlogits_tb, dim3(TB), dim3(256), 0, s, t.logp_w, grad_logp_words, B, T, V, Vp, t.dlogits);
-    if (gemm_to1(h, t, s, TB, H, Vp, t.dlogits, Vp, t.wT_out, Vp, t.dh2_voc, H)) return 1;
+    hipLaunchKernelGGL(k_dlogits_tb, dim3(TB), dim3(256), 0, s, t.logp_w, grad_logp_words, B, T, V, Vp, t.dlogits, dptr(DW_dlogits));
+    if (gemm_to1(h, t, s, TB, H, Vp, t.dlogits, Vp, t.wT_out, Vp, t.dh2_voc, H, dslot(DW_dlogits))) return 1;
     LAUNCHCHK();
 
     // ---- phase A: reverse time.  Per step: k_bwd_head, GEMM 1, k_bwd_mid, k_dalpha, k_attend_bwd, GEMM 2, k_bwd_tail, GEMM 3
@@ -416,16 +494,17 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             q.dh1_c = t.dh1_c; q.dh2_c = t.dh2_c; q.dh2_voc = t.dh2_voc + (size_t)tt * BH;
             q.dc_next = t.dc2_c[cb]; q.gates2 = g2; q.c2 = c2; q.c2_prev = tt > 0 ? c2p : nullptr;
             q.M = B; q.H = H; q.dpre2 = dpre2; q.dc_prev = t.dc2_c[cb ^ 1];
+            q.bm_dga = dptr(tt * 8 + DY_dga); q.bm_dpre2 = dptr(tt * 8 + DY_dpre2);
             hipLaunchKernelGGL(k_bwd_head, dim3(q.gblocks + cdiv((long long)BH, 256)), dim3(256), 0, s, q);
         }
         {   // grouped GEMM 1: dpre2 -> [dh1_a | datt (| dvbar)] , dh2 carry (hh part);  dga -> dg_t
             GemmBuilder g;
             GemmProb& p0 = g.prob(B, H + D, nullptr, H + D);
-            GemmBuilder::seg(p0, dpre2, 4 * H, nullptr, t.wT_ih2, 4 * H, 4 * H);
+            GemmBuilder::seg(p0, dpre2, 4 * H, nullptr, t.wT_ih2, 4 * H, 4 * H, nullptr, dslot(tt * 8 + DY_dpre2));
             GemmProb& p1 = g.prob(B, H, nullptr, H);
-            GemmBuilder::seg(p1, dpre2, 4 * H, nullptr, t.wT_hh2, 4 * H, 4 * H);
+            GemmBuilder::seg(p1, dpre2, 4 * H, nullptr, t.wT_hh2, 4 * H, 4 * H, nullptr, dslot(tt * 8 + DY_dpre2));
             GemmProb& p2 = g.prob(B, H, nullptr, H);
-            GemmBuilder::seg(p2, dga, A, nullptr, t.wT_ga, A, A);
+            GemmBuilder::seg(p2, dga, A, nullptr, t.wT_ga, A, A, nullptr, dslot(tt * 8 + DY_dga));
             const int ns1 = g.finish(h);
             BwdMidArgs q;
             q.nslab = ns1; q.st0 = (long long)B * (H + D); q.st1 = (long long)B * H; q.st2 = (long long)B * H;
@@ -438,7 +517,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             // hh part of the new dh2 carry (the LSTM1-input part is added by the next k_bwd_head from GEMM 3's slabs)
             q.C0 = C0; q.C1 = C1; q.C2 = C2; q.M = B; q.H = H; q.D = D;
             q.datt = t.datt; q.dh1_c = t.dh1_c; q.dh_tot = t.dh_tot; q.dh2_c = t.dh2_c;
-            q.gates1 = g1; q.c1 = c1; q.dq = dpre1 + 5 * H; q.dtc = t.dtc;
+            q.gates1 = g1; q.c1 = c1; q.dq = dpre1 + 5 * H; q.dtc = t.dtc; q.bm_dq = dptr(tt * 8 + DY_dq);
             const int wmax = D > H ? D : H;
             hipLaunchKernelGGL(k_bwd_mid, dim3(cdiv((long long)B * wmax, 256), 3), dim3(256), 0, s, q);
         }
@@ -448,19 +527,21 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             hipLaunchKernelGGL(k_dalpha, dim3(cdiv((long long)B * R1, 4)), dim3(256), 0, s, t.datt, sent, c.regions, c.rmask, c.ridx, slot, B, c.L, c.R, D,
                                t.dalpha);
             if (A >= 512) hipLaunchKernelGGL(k_attend_bwd<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx,
-                               slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws);
+                               slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws,
+                               dptr(tt * 8 + DY_dhA), dptr(tt * 8 + DY_dsent), dptr(tt * 8 + DY_dsa));
             else hipLaunchKernelGGL(k_attend_bwd<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx,
-                               slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws);
+                               slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws,
+                               dptr(tt * 8 + DY_dhA), dptr(tt * 8 + DY_dsent), dptr(tt * 8 + DY_dsa));
         }
         // grouped GEMM 2: [dq | dhA] -> dh1_b ; [dsent | dsa] -> ds_t;  then the sentinel gate and LSTM1 pointwise backward
         {
             GemmBuilder g;
             GemmProb& p0 = g.prob(B, H, nullptr, H);
-            GemmBuilder::seg(p0, dpre1 + 5 * H, 6 * H, nullptr, t.wT_hg, H, H);
-            GemmBuilder::seg(p0, dhA, A, nullptr, t.wT_ha, A, A);
+            GemmBuilder::seg(p0, dpre1 + 5 * H, 6 * H, nullptr, t.wT_hg, H, H, nullptr, dslot(tt * 8 + DY_dq));
+            GemmBuilder::seg(p0, dhA, A, nullptr, t.wT_ha, A, A, nullptr, dslot(tt * 8 + DY_dhA));
             GemmProb& p1 = g.prob(B, H, nullptr, H);
-            GemmBuilder::seg(p1, dsent, D, nullptr, t.wT_sfc, D, D);
-            GemmBuilder::seg(p1, dsa, A, nullptr, t.wT_sa, A, A);
+            GemmBuilder::seg(p1, dsent, D, nullptr, t.wT_sfc, D, D, nullptr, dslot(tt * 8 + DY_dsent));
+            GemmBuilder::seg(p1, dsa, A, nullptr, t.wT_sa, A, A, nullptr, dslot(tt * 8 + DY_dsa));
             const int ns = g.finish(h);
             const long long st = (long long)B * H;
             float *Ca = t.scratch, *Cb = Ca + st * ns;
@@ -468,20 +549,21 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             g.a.p[1].C = Cb; g.a.p[1].slab_stride = st;
             if (g.launch(s, h)) return fail("bwd gemm 2 launch failed");
             hipLaunchKernelGGL(k_bwd_tail, dim3(cdiv((long long)BH, 256)), dim3(256), 0, s, Ca, Cb, ns, st, t.dh_tot, t.dtc, t.dc1_c[cb], g1, c1,
-                               tt > 0 ? c1p : (const float*)nullptr, B, H, dpre1, t.dc1_c[cb ^ 1]);
+                               tt > 0 ? c1p : (const float*)nullptr, B, H, dpre1, t.dc1_c[cb ^ 1], dptr(tt * 8 + DY_dpre1));
         }
         // grouped GEMM 3: dpre1 -> dh1 carry, dh2 carry (LSTM1 input part); its slabs stay in t.scratch for the next k_bwd_head
         ns3 = 0;
         if (tt > 0) {
             GemmBuilder g;
             GemmProb& p1 = g.prob(B, H, nullptr, H);
-            GemmBuilder::seg(p1, dpre1, 6 * H, nullptr, t.wT_hh1, 4 * H, 4 * H);
-            GemmBuilder::seg(p1, dpre1 + 4 * H, 6 * H, nullptr, t.wT_hs, H, H);
+            const int s1 = dslot(tt * 8 + DY_dpre1), sq = dslot(tt * 8 + DY_dq);
+            GemmBuilder::seg(p1, dpre1, 6 * H, nullptr, t.wT_hh1, 4 * H, 4 * H, nullptr, s1);
+            GemmBuilder::seg(p1, dpre1 + 4 * H, 6 * H, nullptr, t.wT_hs, H, H, nullptr, s1);
             if (d.h2_first_lstm) {
                 GemmProb& p0 = g.prob(B, H, nullptr, H);
-                GemmBuilder::seg(p0, dpre1, 6 * H, nullptr, t.wT_ih1, 4 * H, 4 * H);          // rows 0..H-1 of W_ih1^T = h2 columns
-                GemmBuilder::seg(p0, dpre1 + 4 * H, 6 * H, nullptr, t.wT_is, H, H);
-                GemmBuilder::seg(p0, dpre1 + 5 * H, 6 * H, nullptr, t.wT_ig, H, H);
+                GemmBuilder::seg(p0, dpre1, 6 * H, nullptr, t.wT_ih1, 4 * H, 4 * H, nullptr, s1);          // rows 0..H-1 of W_ih1^T = h2 columns
+                GemmBuilder::seg(p0, dpre1 + 4 * H, 6 * H, nullptr, t.wT_is, H, H, nullptr, s1);
+                GemmBuilder::seg(p0, dpre1 + 5 * H, 6 * H, nullptr, t.wT_ig, H, H, nullptr, sq);
             }
             ns3 = g.finish(h);
             g.a.p[0].C = t.scratch; g.a.p[0].slab_stride = st3;
@@ -506,6 +588,11 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     transpose(h, s, h2cur, H, TB, H, t.tX_h2, TBp);
     transpose(h, s, c.vbar, D, B, D, t.tX_vbar, Bp);
     if (NV > 0) transpose(h, s, c.regions, (long long)D, NV, D, t.tX_reg, (long long)NVp, c.vlist);
+    if (h2b) {
+        h2_images(h, t, s, t.n_wT_imgs, t.imgs.size(), NV > 0 ? (long long)D * NVp : 0);      // (tX_reg is the last one: D x NVp in use)
+        hipLaunchKernelGGL(k_h2_dyn_fold, dim3(1), dim3(64), 0, s, dyn, T);
+    }
+    const int sP1 = dslot(DW_step + DY_dpre1), sQ = dslot(DW_step + DY_dq), sP2 = dslot(DW_step + DY_dpre2);
     transpose(h, s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp);
     transpose(h, s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp);
     transpose(h, s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp);
@@ -521,6 +608,10 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         dP_rows = t.dP_bank;
     }
     if (NV > 0) transpose(h, s, dP_rows, (long long)A, NV, A, t.tY_dP, (long long)NVp, c.vlist);
+    if (h2b && NV > 0) {
+        const long long ndp = (long long)(c.ridx ? (size_t)c.n_img * c.Rb : (size_t)RL) * A;
+        hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<long long>(1024, cdiv(ndp, 1024))), dim3(256), 0, s, dP_rows, ndp, reinterpret_cast<unsigned*>(dyn + DW_dP));
+    }
     hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 6 * H, 256)), dim3(256), 0, s, t.dpre1, T, (long long)B * 6 * H, t.dpre1sum);
     transpose(h, s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
     LAUNCHCHK();
@@ -536,59 +627,60 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         const int r0[3] = {0, 4 * H, 5 * H}, nr[3] = {4 * H, H, H};
         for (int i = 0; i < 3; ++i) {
             const float* dy = t.tY_dpre1 + (size_t)r0[i] * TBp;
-            if (d.h2_first_lstm && gemm_to1(h, t, s, nr[i], H, TBp, dy, TBp, t.tX_h2prev, TBp, Gw[i], in1)) return 1;
-            if (gemm_to1(h, t, s, nr[i], D, Bp, t.tY_dpre1sum + (size_t)r0[i] * Bp, Bp, t.tX_vbar, Bp, Gw[i] + voff, in1)) return 1;
-            if (gemm_to1(h, t, s, nr[i], E, TBp, dy, TBp, t.tX_x, TBp, Gw[i] + xoff, in1)) return 1;
+            const int sa = i == 2 ? sQ : sP1;
+            if (d.h2_first_lstm && gemm_to1(h, t, s, nr[i], H, TBp, dy, TBp, t.tX_h2prev, TBp, Gw[i], in1, sa)) return 1;
+            if (gemm_to1(h, t, s, nr[i], D, Bp, t.tY_dpre1sum + (size_t)r0[i] * Bp, Bp, t.tX_vbar, Bp, Gw[i] + voff, in1, dslot(DW_dpre1sum))) return 1;
+            if (gemm_to1(h, t, s, nr[i], E, TBp, dy, TBp, t.tX_x, TBp, Gw[i] + xoff, in1, sa)) return 1;
         }
     }
     HIPCHK(hipEventRecord(t.bucket_ev[0], s));
     // ---- bucket 1: lstm_cell_2
-    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2)) return 1;
-    if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2)) return 1;
+    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2, sP2)) return 1;
+    if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2, sP2)) return 1;
     if (d.img_second_lstm) {
         hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 4 * H, 256)), dim3(256), 0, s, t.dpre2, T, (long long)B * 4 * H, t.dpre2sum);
         transpose(h, s, t.dpre2sum, 4 * H, B, 4 * H, t.tY_dpre2sum, Bp);
-        if (gemm_to1(h, t, s, 4 * H, D, Bp, t.tY_dpre2sum, Bp, t.tX_vbar, Bp, G[g_Wih2] + H + D, in2)) return 1;
+        if (gemm_to1(h, t, s, 4 * H, D, Bp, t.tY_dpre2sum, Bp, t.tX_vbar, Bp, G[g_Wih2] + H + D, in2, dslot(DW_dpre2sum))) return 1;
     }
-    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H)) return 1;
+    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H, sP2)) return 1;
     colsum(t, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2]);
     HIPCHK(hipMemcpyAsync(G[g_bhh2], G[g_bih2], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipEventRecord(t.bucket_ev[1], s));
     // ---- bucket 2: out_fc and the embedding
-    if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H)) return 1;
+    if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H, dslot(DW_dlogits))) return 1;
     colsum(t, s, t.dlogits, (long long)Vp, TB, V, G[g_bout]);
     {   // embedding: dx = dpre1 . [W_ih1 ; W_is ; W_ig][:, x columns], summed onto the rows that were looked up (ordered, no atomics)
-        SegSpec sg[3] = {{t.dpre1, 6 * H, t.wT_ih1 + (size_t)xoff * 4 * H, 4 * H, 4 * H},
-                         {t.dpre1 + 4 * H, 6 * H, t.wT_is + (size_t)xoff * H, H, H},
-                         {t.dpre1 + 5 * H, 6 * H, t.wT_ig + (size_t)xoff * H, H, H}};
+        SegSpec sg[3] = {{t.dpre1, 6 * H, t.wT_ih1 + (size_t)xoff * 4 * H, 4 * H, 4 * H, sP1},
+                         {t.dpre1 + 4 * H, 6 * H, t.wT_is + (size_t)xoff * H, H, H, sP1},
+                         {t.dpre1 + 5 * H, 6 * H, t.wT_ig + (size_t)xoff * H, H, H, sQ}};
         if (gemm_to(h, t, s, TB, E, sg, 3, t.dx_all, E)) return 1;
         HIPCHK(hipMemsetAsync(G[g_embed], 0, (size_t)V * E * sizeof(float), s));
         hipLaunchKernelGGL(k_embed_grad_rows, dim3(TB), dim3(256), 0, s, t.dx_all, t.word32, TB, E, G[g_embed]);
     }
     HIPCHK(hipEventRecord(t.bucket_ev[2], s));
     // ---- bucket 3: the recurrent LSTM1 / sentinel-gate weights, all LSTM1 / gate biases, s_fc, att_va
-    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H)) return 1;
-    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H)) return 1;
+    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H, sP1)) return 1;
+    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H, sP1)) return 1;
     colsum(t, s, t.dpre1, (long long)6 * H, TB, 4 * H, G[g_bih1]);
     HIPCHK(hipMemcpyAsync(G[g_bhh1], G[g_bih1], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     colsum(t, s, t.dpre1 + 4 * H, (long long)6 * H, TB, H, G[g_bis]);
     HIPCHK(hipMemcpyAsync(G[g_bhs], G[g_bis], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
     colsum(t, s, t.dpre1 + 5 * H, (long long)6 * H, TB, H, G[g_big]);
     HIPCHK(hipMemcpyAsync(G[g_bhg], G[g_big], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (gemm_to1(h, t, s, D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H)) return 1;
+    if (gemm_to1(h, t, s, D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H, dslot(DW_step + DY_dsent))) return 1;
     colsum(t, s, t.dsent_all, (long long)D, TB, D, G[g_bsfc]);
     // att_va: dP^T (A, NV) x regions^T (D, NV) over the non-padding rows
     if (NV > 0) {
-        if (gemm_to1(h, t, s, A, D, NVp, t.tY_dP, NVp, t.tX_reg, NVp, G[g_Wva], D)) return 1;
+        if (gemm_to1(h, t, s, A, D, NVp, t.tY_dP, NVp, t.tX_reg, NVp, G[g_Wva], D, dslot(DW_dP))) return 1;
     } else {
         HIPCHK(hipMemsetAsync(G[g_Wva], 0, (size_t)A * D * sizeof(float), s));
     }
     HIPCHK(hipEventRecord(t.bucket_ev[3], s));
     // ---- bucket 4 (the tail, 3.5 M floats): W1_hg, att_ha, att_sa, att_ga and the three score vectors
-    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H)) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H)) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H)) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H)) return 1;
+    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H, sQ)) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H, dslot(DW_step + DY_dhA))) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H, dslot(DW_step + DY_dsa))) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H, dslot(DW_step + DY_dga))) return 1;
     colsum(t, s, t.dwa_rows, (long long)A, TB, A, G[g_wa]);
     colsum(t, s, t.dws_rows, (long long)A, TB, A, G[g_ws]);
     colsum(t, s, t.dwg_rows, (long long)A, TB, A, G[g_wg]);

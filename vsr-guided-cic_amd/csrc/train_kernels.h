@@ -22,6 +22,35 @@ __device__ __forceinline__ uint16_t to_bf16_bits(float x) {
     const f2 v = {x, 0.f};
     return (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2)) & 0xffffu);
 }
+// f16x2 flavour (gemm_h2.h): the GEMMs of the backward pass scale their A operands - gradients, whose range is only known once they
+// exist - by a bound the PRODUCING kernel folds into a slot of the exponent table: max |x| over the workgroup, one atomicMax per
+// workgroup (bit patterns of non-negative floats order like integers).  bm == nullptr: flavour off.  Every thread of the workgroup
+// must reach the call (threads outside the range bring 0).
+template <int NV>
+__device__ __forceinline__ void block_absmax_to(const float (&m_in)[NV], int* const (&bm)[NV]) {
+    __shared__ float wm[NV][16];
+    float m[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        m[v] = m_in[v];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m[v] = fmaxf(m[v], __shfl_xor(m[v], o, 64));
+        if ((threadIdx.x & 63) == 0) wm[v][threadIdx.x >> 6] = m[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float r = 0.f;
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) r = fmaxf(r, wm[threadIdx.x][i]);
+        if (r > 0.f) atomicMax(bm[threadIdx.x], __float_as_int(r));
+    }
+}
+__device__ __forceinline__ void block_absmax_to(float m, int* bm) {
+    const float mm[1] = {m};
+    int* const bb[1] = {bm};
+    block_absmax_to<1>(mm, bb);
+}
+
 template <bool GATHER, bool BF16>
 __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int R, int C,
                                                      float* __restrict__ out, long long ld_out, uint16_t* __restrict__ out16) {
@@ -304,12 +333,13 @@ __global__ __launch_bounds__(NT) void k_attend_bwd(const float* __restrict__ dat
                                                     int M, int L, int R, int A, int D, const float* __restrict__ w_a,
                                                     const float* __restrict__ w_s, float* __restrict__ dsent, float* __restrict__ dsa,
                                                     float* __restrict__ dhA, float* __restrict__ dP, float* __restrict__ dwa_rows,
-                                                    float* __restrict__ dws_rows) {
+                                                    float* __restrict__ dws_rows, int* bm_dhA, int* bm_dsent, int* bm_dsa) {
     extern __shared__ float sm[];
     float* da = sm;                 // R+1: dalpha, then dz
     float* red = sm + R + 1;        // 8
     const int row = xcd_item(M);
-    if (row < 0) return;
+    if (row < 0) return;            // (whole workgroups)
+    float mx[3] = {0.f, 0.f, 0.f};  // max |dhA|, |dsent|, |dsa| of this row (f16x2 bounds)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = slot ? slot[row] : fixed_slot;
     const long long sl = (long long)row * L + k;
@@ -323,7 +353,9 @@ __global__ __launch_bounds__(NT) void k_attend_bwd(const float* __restrict__ dat
     const float a0 = al[0];
     for (int d = tid * 4; d < D; d += 4 * NT) {
         const float4 a = *reinterpret_cast<const float4*>(g + d);
-        *reinterpret_cast<float4*>(dsent + (long long)row * D + d) = make_float4(a0 * a.x, a0 * a.y, a0 * a.z, a0 * a.w);
+        const float4 o = make_float4(a0 * a.x, a0 * a.y, a0 * a.z, a0 * a.w);
+        *reinterpret_cast<float4*>(dsent + (long long)row * D + d) = o;
+        mx[1] = fmaxf(fmaxf(mx[1], fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
     __syncthreads();
     if (wave == 0) {
@@ -380,9 +412,15 @@ __global__ __launch_bounds__(NT) void k_attend_bwd(const float* __restrict__ dat
         const float ths = tanhf(sa[(long long)row * A + a] + h);
         const float dus = da[0] * w_s[a] * (1.f - ths * ths);
         dsa[(long long)row * A + a] = dus;
-        dhA[(long long)row * A + a] += dh + dus;
+        const float dhn = dhA[(long long)row * A + a] + (dh + dus);
+        dhA[(long long)row * A + a] = dhn;
+        mx[0] = fmaxf(mx[0], fabsf(dhn)); mx[2] = fmaxf(mx[2], fabsf(dus));
         dwa_rows[(long long)row * A + a] = dwa;
         dws_rows[(long long)row * A + a] = da[0] * ths;
+    }
+    if (bm_dhA) {
+        int* const bb[3] = {bm_dhA, bm_dsent, bm_dsa};
+        block_absmax_to<3>(mx, bb);
     }
 }
 
@@ -401,47 +439,55 @@ struct BwdHeadArgs {
     float* dh1_c; const float* dh2_c; const float* dh2_voc;
     const float* dc_next; const float* gates2; const float* c2; const float* c2_prev;
     int M, H; float* dpre2; float* dc_prev;
+    int* bm_dga; int* bm_dpre2;       // f16x2 bound slots of dga / dpre2 (null: flavour off)
 };
 __global__ __launch_bounds__(256) void k_bwd_head(const BwdHeadArgs q) {
     if ((int)blockIdx.x < q.gblocks) {
         const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (row >= q.M) return;
-        const int lane = threadIdx.x & 63, A = q.A;
-        const float l0 = q.lg[row * q.lg_stride], l1 = q.lg[row * q.lg_stride + 1];
-        const float g0 = q.dlg[row * q.lg_stride], g1 = q.dlg[row * q.lg_stride + 1];
-        const float tot = g0 + g1;
-        const float dzg = g0 - expf(l0) * tot, dzs = g1 - expf(l1) * tot;
-        for (int a = lane; a < A; a += 64) {
-            const float th = tanhf(q.ga[(long long)row * A + a] + q.hA[(long long)row * A + a]);
-            const float du = dzg * q.w_g[a] * (1.f - th * th);
-            q.dga[(long long)row * A + a] = du;
-            q.dhA[(long long)row * A + a] = du;               // first writer of dhA for this step
-            q.dwg_rows[(long long)row * A + a] = dzg * th;    // summed over rows later (k_colsum)
+        float mx = 0.f;
+        if (row < q.M) {
+            const int lane = threadIdx.x & 63, A = q.A;
+            const float l0 = q.lg[row * q.lg_stride], l1 = q.lg[row * q.lg_stride + 1];
+            const float g0 = q.dlg[row * q.lg_stride], g1 = q.dlg[row * q.lg_stride + 1];
+            const float tot = g0 + g1;
+            const float dzg = g0 - expf(l0) * tot, dzs = g1 - expf(l1) * tot;
+            for (int a = lane; a < A; a += 64) {
+                const float th = tanhf(q.ga[(long long)row * A + a] + q.hA[(long long)row * A + a]);
+                const float du = dzg * q.w_g[a] * (1.f - th * th);
+                q.dga[(long long)row * A + a] = du;
+                q.dhA[(long long)row * A + a] = du;               // first writer of dhA for this step
+                q.dwg_rows[(long long)row * A + a] = dzg * th;    // summed over rows later (k_colsum)
+                mx = fmaxf(mx, fabsf(du));
+            }
+            if (lane == 0) q.dzsum[row] = dzs;
         }
-        if (lane == 0) q.dzsum[row] = dzs;
+        if (q.bm_dga) block_absmax_to(mx, q.bm_dga);
         return;
     }
     const int H = q.H;
     const long long i = (long long)(blockIdx.x - q.gblocks) * 256 + threadIdx.x;
-    if (i >= (long long)q.M * H) return;
-    const int row = (int)(i / H), j = (int)(i % H);
-    float carry = q.dh2_c[i];
-    if (q.nslab3 > 0) {
-        q.dh1_c[i] = slab_sum(q.s_h1 + i, q.nslab3, q.stride3);
-        if (q.s_h2) carry = slab_sum(q.s_h2 + i, q.nslab3, q.stride3, carry);
+    float mx = 0.f;
+    if (i < (long long)q.M * H) {
+        const int row = (int)(i / H), j = (int)(i % H);
+        float carry = q.dh2_c[i];
+        if (q.nslab3 > 0) {
+            q.dh1_c[i] = slab_sum(q.s_h1 + i, q.nslab3, q.stride3);
+            if (q.s_h2) carry = slab_sum(q.s_h2 + i, q.nslab3, q.stride3, carry);
+        }
+        const float dhv = q.dh2_voc[i] + carry + 0.f;
+        const float* g = q.gates2 + (long long)row * 4 * H + j;
+        const float ig = g[0], fg = g[H], gg = g[2LL * H], og = g[3LL * H];
+        const float tc = tanhf(q.c2[i]);
+        const float dtc = dhv * og;
+        const float dc = q.dc_next[i] + dtc * (1.f - tc * tc);
+        float* d = q.dpre2 + (long long)row * 4 * H + j;
+        const float d0 = dc * gg * ig * (1.f - ig), d1 = dc * (q.c2_prev ? q.c2_prev[i] : 0.f) * fg * (1.f - fg);
+        const float d2 = dc * ig * (1.f - gg * gg), d3 = dhv * tc * og * (1.f - og);
+        d[0] = d0; d[H] = d1; d[2LL * H] = d2; d[3LL * H] = d3;
+        q.dc_prev[i] = dc * fg;
+        mx = fmaxf(fmaxf(fabsf(d0), fabsf(d1)), fmaxf(fabsf(d2), fabsf(d3)));
     }
-    const float dhv = q.dh2_voc[i] + carry + 0.f;
-    const float* g = q.gates2 + (long long)row * 4 * H + j;
-    const float ig = g[0], fg = g[H], gg = g[2LL * H], og = g[3LL * H];
-    const float tc = tanhf(q.c2[i]);
-    const float dtc = dhv * og;
-    const float dc = q.dc_next[i] + dtc * (1.f - tc * tc);
-    float* d = q.dpre2 + (long long)row * 4 * H + j;
-    d[0] = dc * gg * ig * (1.f - ig);
-    d[H] = dc * (q.c2_prev ? q.c2_prev[i] : 0.f) * fg * (1.f - fg);
-    d[2LL * H] = dc * ig * (1.f - gg * gg);
-    d[3LL * H] = dhv * tc * og * (1.f - og);
-    q.dc_prev[i] = dc * fg;
+    if (q.bm_dpre2) block_absmax_to(mx, q.bm_dpre2);
 }
 
 // k_bwd_mid (after GEMM 1; grid.y = part): 0: datt = sum of the slabs' columns [H, H+D);  1: dg_t = sum of the att_ga slabs,
@@ -452,6 +498,7 @@ struct BwdMidArgs {
     int M, H, D;
     float* datt; const float* dh1_c; float* dh_tot; float* dh2_c;
     const float* gates1; const float* c1; float* dq; float* dtc;          // gates1 (M,6H); dq window of ld 6H
+    int* bm_dq;                                                           // f16x2 bound slot of dq (null: flavour off)
 };
 __global__ __launch_bounds__(256) void k_bwd_mid(const BwdMidArgs q) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -462,15 +509,21 @@ __global__ __launch_bounds__(256) void k_bwd_mid(const BwdMidArgs q) {
         q.datt[i] = slab_sum(q.C0 + (long long)r * (H + D) + H + c, q.nslab, q.st0);
         return;
     }
-    if (i >= (long long)q.M * H) return;
+    const bool live = i < (long long)q.M * H;
     const int r = (int)(i / H), c = (int)(i % H);
     if (blockIdx.y == 1) {
-        const float d = slab_sum(q.C2 + i, q.nslab, q.st2);
-        const float tc = tanhf(q.c1[i]);
-        const float gg = q.gates1[(long long)r * 6 * H + 5LL * H + c];
-        q.dq[(long long)r * 6 * H + c] = d * tc * gg * (1.f - gg);
-        q.dtc[i] = d * gg;
-    } else {
+        float mx = 0.f;
+        if (live) {
+            const float d = slab_sum(q.C2 + i, q.nslab, q.st2);
+            const float tc = tanhf(q.c1[i]);
+            const float gg = q.gates1[(long long)r * 6 * H + 5LL * H + c];
+            const float o = d * tc * gg * (1.f - gg);
+            q.dq[(long long)r * 6 * H + c] = o;
+            q.dtc[i] = d * gg;
+            mx = fabsf(o);
+        }
+        if (q.bm_dq) block_absmax_to(mx, q.bm_dq);
+    } else if (live) {
         q.dh_tot[i] = slab_sum(q.C0 + (long long)r * (H + D) + c, q.nslab, q.st0, q.dh1_c[i]);
         q.dh2_c[i] = slab_sum(q.C1 + i, q.nslab, q.st1);
     }
@@ -482,26 +535,30 @@ __global__ __launch_bounds__(256) void k_bwd_tail(const float* __restrict__ Ca, 
                                                   const float* __restrict__ dh_tot, const float* __restrict__ dtc_in,
                                                   const float* __restrict__ dc_next, const float* __restrict__ gates1,
                                                   const float* __restrict__ c1, const float* __restrict__ c1_prev, int M, int H,
-                                                  float* __restrict__ dpre1, float* __restrict__ dc_prev) {
+                                                  float* __restrict__ dpre1, float* __restrict__ dc_prev, int* bm_dpre1) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)M * H) return;
-    const int row = (int)(i / H), j = (int)(i % H);
-    const float dhv = slab_sum(Ca + i, nslab, st, dh_tot[i]);
-    const float ds = slab_sum(Cb + i, nslab, st);
-    const float* g = gates1 + (long long)row * 6 * H + j;
-    const float ig = g[0], fg = g[H], gg = g[2LL * H], og = g[3LL * H], sg = g[4LL * H];
-    const float tc = tanhf(c1[i]);
-    float* d = dpre1 + (long long)row * 6 * H + j;
-    d[4LL * H] = ds * tc * sg * (1.f - sg);
-    const float extra = dtc_in[i] + ds * sg;
-    float dtc = dhv * og;
-    dtc += extra;
-    const float dc = dc_next[i] + dtc * (1.f - tc * tc);
-    d[0] = dc * gg * ig * (1.f - ig);
-    d[H] = dc * (c1_prev ? c1_prev[i] : 0.f) * fg * (1.f - fg);
-    d[2LL * H] = dc * ig * (1.f - gg * gg);
-    d[3LL * H] = dhv * tc * og * (1.f - og);
-    dc_prev[i] = dc * fg;
+    float mx = 0.f;
+    if (i < (long long)M * H) {
+        const int row = (int)(i / H), j = (int)(i % H);
+        const float dhv = slab_sum(Ca + i, nslab, st, dh_tot[i]);
+        const float ds = slab_sum(Cb + i, nslab, st);
+        const float* g = gates1 + (long long)row * 6 * H + j;
+        const float ig = g[0], fg = g[H], gg = g[2LL * H], og = g[3LL * H], sg = g[4LL * H];
+        const float tc = tanhf(c1[i]);
+        float* d = dpre1 + (long long)row * 6 * H + j;
+        const float d4 = ds * tc * sg * (1.f - sg);
+        d[4LL * H] = d4;
+        const float extra = dtc_in[i] + ds * sg;
+        float dtc = dhv * og;
+        dtc += extra;
+        const float dc = dc_next[i] + dtc * (1.f - tc * tc);
+        const float d0 = dc * gg * ig * (1.f - ig), d1 = dc * (c1_prev ? c1_prev[i] : 0.f) * fg * (1.f - fg);
+        const float d2 = dc * ig * (1.f - gg * gg), d3 = dhv * tc * og * (1.f - og);
+        d[0] = d0; d[H] = d1; d[2LL * H] = d2; d[3LL * H] = d3;
+        dc_prev[i] = dc * fg;
+        mx = fmaxf(fmaxf(fmaxf(fabsf(d0), fabsf(d1)), fmaxf(fabsf(d2), fabsf(d3))), fabsf(d4));
+    }
+    if (bm_dpre1) block_absmax_to(mx, bm_dpre1);      // (rows [0, 5H) of dpre1; the gate block [5H, 6H) is k_bwd_mid's dq)
 }
 
 // (B, T) int64 captions / slot traces -> (T, B) int32 step-major copies, plus the (b, t)-ordered row list of the saved

@@ -29,6 +29,7 @@
 #include "gemm_x3.h"
 #include "gemm_x3s.h"
 #include "gemm_h2.h"
+#include "gemm_h2a.h"
 #include "kernels.h"
 #include "train_kernels.h"
 
@@ -112,11 +113,19 @@ struct vsr_handle {
     // (M = 65) 2.61 ms either way; 48 - greedy 668 k, the shard 2.75 ms
     int h2s_max = 80, h2s_slots = 512, h2s_min = 8, h2s_ns = 1;
     int h2_aligned_min = 4;
+    // the producers of the decoder's A operands (h1, h2, s_t, g_t, the attended vector) write fp16-pair images next to the fp32 values
+    // and launches whose A operands all have one take the all-DMA kernel (gemm_h2a.h); VSR_H2_AIMG=0: in-kernel split of fp32 A only
+    bool h2_aimg = true;
+    int h2a_max_small = 128;          // launches of at most this many rows (and more than h2s_max) : 128 x 128 tiles of the all-DMA kernel
+    std::vector<H2Range> h2t;         // the training pass's transposed operands (vsr_train_forward registers the images of its workspace)
     const H2Range* map_h2(const float* p) const {
         for (const H2Range& r : h2)
             if (p >= r.lo && p < r.hi) return &r;
+        for (const H2Range& r : h2t)
+            if (p >= r.lo && p < r.hi) return &r;
         return nullptr;
     }
+    int h2_slot_of(const float* p) const { const H2Range* r = map_h2(p); return r ? r->slot : 0; }
     bool x3_on = true;                // launches of >= gemm_x3_min_rows rows: fp32 products through three bf16 terms per operand (gemm_f32x3.h); fp32 operands, no copies.  vsr_set_gemm_mode(h, 0): exact fma chain everywhere
     std::vector<Bf16Range> b16;        // weights (refresh) + the training pass's transposed operands (carve_train)
     size_t b16_weights = 0;            // entries of b16 that belong to the weights
@@ -253,10 +262,10 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     c.pre1 = b.take<float>(M * 6 * H * 8);
     b.off = (b.off + 15) & ~size_t(15);
     for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j) c.st16[i][j] = b.take<uint16_t>((M * H + 7) & ~size_t(7));
-    c.s_t16 = b.take<uint16_t>((M * H + 7) & ~size_t(7));
-    c.g_t16 = b.take<uint16_t>((M * H + 7) & ~size_t(7));
-    c.att16 = b.take<uint16_t>((M * D + 7) & ~size_t(7));
+        for (int j = 0; j < 2; ++j) c.st16[i][j] = b.take<uint16_t>(2 * ((M * H + 7) & ~size_t(7)));      // (bf16: 2 bytes per element; fp16 pairs: 4)
+    c.s_t16 = b.take<uint16_t>(2 * ((M * H + 7) & ~size_t(7)));
+    c.g_t16 = b.take<uint16_t>(2 * ((M * H + 7) & ~size_t(7)));
+    c.att16 = b.take<uint16_t>(2 * ((M * D + 7) & ~size_t(7)));
     return (b.off + 255) & ~size_t(255);
 }
 
@@ -345,13 +354,32 @@ struct GemmBuilder {
                         S.W = r->img + (S.W - r->lo);
                     }
                 ah.exps = h->h2_exps;
+                // all-DMA kernel (gemm_h2a.h): every A operand has an fp16-pair image too - written by its producer (GemmSeg::A16 in this
+                // flavour) or a registered one (the embedding table)
+                bool aimg = h->h2_aimg;
+                for (int i = 0; i < ah.nprob && aimg; ++i)
+                    for (int sg = 0; sg < ah.p[i].nseg && aimg; ++sg) {
+                        const GemmSeg& S = ah.p[i].seg[sg];
+                        const H2Range* ra = S.A16 ? nullptr : h->map_h2(S.A);
+                        aimg = (S.lda % 8 == 0) && (S.A16 ? (reinterpret_cast<uintptr_t>(S.A16) & 31) == 0
+                                                          : (ra && ra->slot == (S.exp_idx >> 16) && (S.A - ra->lo) % 8 == 0));
+                    }
+                auto with_a_images = [&](GemmArgs& g) {
+                    for (int i = 0; i < g.nprob; ++i)
+                        for (int sg = 0; sg < g.p[i].nseg; ++sg) {
+                            GemmSeg& S = g.p[i].seg[sg];
+                            if (S.A16) S.A = reinterpret_cast<const float*>(S.A16);
+                            else { const H2Range* ra = h->map_h2(S.A); S.A = ra->img + (S.A - ra->lo); }
+                        }
+                };
                 const int slots = h->gemm_slots_bf16;
                 if (maxM <= h->h2s_max && maxM <= 128) {
                     GemmArgs as = ah;
                     if (const int ns = gemm_plan_aligned(as, h->h2s_slots, h->h2s_min, 128, h2s_bn(h->h2s_ns), H2_BK)) { a = as; big = 36; x3s_mt = (maxM + 15) / 16; return ns; }
                 }
-                big = 35;
+                big = aimg ? 37 : 35;
                 a = ah;
+                if (aimg) with_a_images(a);
                 auto aligned_eff = [&](GemmArgs& g) {
                     int T = 1;
                     for (int i = 0; i < g.nprob; ++i) T = std::max(T, (g.p[i].ktiles + g.p[i].split - 1) / g.p[i].split);
@@ -453,7 +481,7 @@ struct GemmBuilder {
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     if (stale_w) return fail("bf16 mode: a GEMM launch names a transposed operand that only exists as a bf16 image but cannot take the bf16 kernel (K / leading dimensions must be multiples of 8)");
-    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : (big == 33 || big == 35) ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34 / 36: 256 = X3S_THREADS = H2S_THREADS)
+    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : (big == 33 || big == 35 || big == 37) ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34 / 36: 256 = X3S_THREADS = H2S_THREADS)
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
     if (big == 36) {
@@ -463,7 +491,9 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
             default: if (h->h2s_ns == 2) hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 2>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 1>), grid, block, 0, s, a); break;
         }
 #undef H2S_CASE
-    } else if (big == 35 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2>), grid, block, 0, s, a);
+    } else if (big == 37 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 2>), grid, block, 0, s, a);
+    else if (big == 37) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1>), grid, block, 0, s, a);
+    else if (big == 35 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 35) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 1>), grid, block, 0, s, a);
     else if (big == 34) {
         switch (x3s_mt) {
@@ -543,6 +573,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_H2S_MIN")) h->h2s_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2S_NS")) h->h2s_ns = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
+    if (const char* e = getenv("VSR_H2_AIMG")) h->h2_aimg = atoi(e) != 0;
     if (const char* e = getenv("VSR_X3S_SLOTS")) h->x3s_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_X3S_MIN")) h->x3s_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_X3_ALIGNED")) { h->x3_aligned_wide = atoi(e) / 10; h->x3_aligned_skinny = atoi(e) % 10; }
@@ -626,7 +657,7 @@ extern "C" int vsr_bind_weights(vsr_handle* h, const vsr_weights* w) {
     }
     if (h->h2_on) {                   // ... and the fp16-pair images (vsr_refresh_h2_weights)
         h->h2_on = false;
-        h->h2.clear();
+        h->h2.clear(); h->h2t.clear();
         h->prepared = false;
     }
     return 0;
@@ -732,7 +763,9 @@ extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t byte
 
 // ---- f16x2 flavour (gemm_h2.h): fp16-pair images of the 14 weight matrices the GEMMs multiply by, their power-of-two scales, and the
 // bounds of the A operands that depend on the weights only (embedding rows, the sentinel vector).  fp32 stays the master copy.
-static const size_t H2_HEAD = 1024;      // bytes: exponent table | bound table | index scratch
+static const size_t H2_HEAD = 4096;      // bytes: exponent table | bound table | index scratch | from byte 1024: H2_NDYN dynamic slots (ints H2_DYN0 ..)
+constexpr int H2_NDYN = 512;             // 64 blocks of 8: one block per timestep of the backward pass (bounds of its gradient operands), the last two for the whole-pass operands
+static_assert(H2_DYN0 * 4 + H2_NDYN * 4 <= 4096, "dynamic slots inside the head");
 extern "C" size_t vsr_h2_weight_bytes(const vsr_handle* h) {
     if (!h) return 0;
     const float* p[B16_NW]; size_t n[B16_NW];
@@ -741,6 +774,7 @@ extern "C" size_t vsr_h2_weight_bytes(const vsr_handle* h) {
     b16_weight_list(h->d, none, p, n);
     size_t tot = H2_HEAD;
     for (int i = 0; i < B16_NW; ++i) tot += ((n[i] + 7) & ~size_t(7)) * sizeof(float);
+    tot += (((size_t)h->d.vocab_size * h->d.input_encoding_size + 7) & ~size_t(7)) * sizeof(float);      // the embedding table (an A operand: gemm_h2a.h)
     return tot + 256;
 }
 __global__ void k_h2_head_init(int* exps, unsigned* bounds, int* idx) {
@@ -766,7 +800,7 @@ extern "C" int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes,
     if (!buffer) {                                          // back to f32x3 for every launch
         if (h->h2_on) { h->xproj = nullptr; invalidate_train_ctx(h->tc); h->prepared = false; }
         h->h2_on = false;
-        h->h2.clear();
+        h->h2.clear(); h->h2t.clear();
         return 0;
     }
     if (!h->bound) return fail("vsr_refresh_h2_weights: weights not bound");
@@ -816,8 +850,15 @@ extern "C" int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes,
         h->h2.push_back(H2Range{p[i], p[i] + n[i], out + off, i});
         off += (long long)n8;
     }
-    mc.blk[B16_NW] = blocks;
-    mc.nt = B16_NW;
+    {   // the embedding table: an A operand (gathered rows) of the all-DMA kernel, scaled by its own bound class
+        const size_t n8 = ((size_t)ne + 7) & ~size_t(7);
+        mc.src[B16_NW] = h->w.embed_weight; mc.n[B16_NW] = (long long)n8; mc.dst_off[B16_NW] = off; mc.slot[B16_NW] = H2A_EMBED; mc.blk[B16_NW] = blocks;
+        blocks += cdiv((long long)n8, 8 * 256);
+        h->h2.push_back(H2Range{h->w.embed_weight, h->w.embed_weight + ne, out + off, H2A_EMBED});
+        off += (long long)n8;
+    }
+    mc.blk[B16_NW + 1] = blocks;
+    mc.nt = B16_NW + 1;
     hipLaunchKernelGGL(k_f32_to_h2_multi, dim3(blocks), dim3(256), 0, s, mc, reinterpret_cast<uint32_t*>(out), exps);
     LAUNCHCHK();
     h->h2_exps = exps; h->h2_bounds = bounds;
@@ -1051,7 +1092,11 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     float *h1o = so[0], *c1o = so[1], *h2o = so[2], *c2o = so[3];
     float *h1n = sn[0], *c1n = sn[1], *h2n = sn[2], *c2n = sn[3];
     // bf16 images of the A operands (bf16 mode): the producers below write them, the GEMM segments name them
-    const bool sh = h->bf16_on && h->bf16_a16;
+    // ... or fp16-pair images (f16x2 flavour, gemm_h2a.h): isc = the scale of the unit-bounded ones (2^15), the attended vector's from the table
+    const bool sh2 = h->h2_on && !h->bf16_on && h->x3_on && h->h2_aimg;
+    const bool sh = (h->bf16_on && h->bf16_a16) || sh2;
+    const float isc = sh2 ? 32768.f : 0.f;
+    const int* att_exp = sh2 ? h->h2_exps + H2A_ATT : nullptr;
     const bool sh_old = sh && c.st16_ok[io.cur];
     uint16_t *h1n16 = sh ? c.st16[io.cur ^ 1][0] : nullptr, *h2n16 = sh ? c.st16[io.cur ^ 1][1] : nullptr;
     const uint16_t *h1o16 = sh_old ? c.st16[io.cur][0] : nullptr, *h2o16 = sh_old ? c.st16[io.cur][1] : nullptr;
@@ -1060,7 +1105,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     // ---- S1
     if (io.s1_from_prev) {
         hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.pre1, c.pre1_ns, c.pre1_stride, c.vproj, io.rpi,
-                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, c.pre1_nblk, 1, h1n16, s_t16);
+                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, c.pre1_nblk, 1, h1n16, s_t16, isc);
     } else {
         const bool xc = h->xproj != nullptr;            // embedding part comes from the decode cache
         GemmBuilder g;
@@ -1086,7 +1131,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
             if (g.launch(s, h)) return fail("S1 gemm launch failed");
         }
         hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj, io.rpi,
-                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, nblk, 0, h1n16, s_t16);
+                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, nblk, 0, h1n16, s_t16, isc);
     }
     // ---- S2
     {
@@ -1109,12 +1154,12 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[2].slab_stride = g.a.p[3].slab_stride = stride_b;
         if (g.launch(s, h)) return fail("S2 gemm launch failed");
         // k_gate2's work (g_t, hA, s_a, sentinel from the S2 slabs) is done by the attention kernel's row blocks themselves
-        const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16};
+        const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16, isc};
         const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
         if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16);
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16, att_exp);
         else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16);
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16, att_exp);
     }
     // ---- S5
     GateLogitArgs gate_args;
@@ -1133,7 +1178,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[1].nslab = gemm_tight_slabs(g.a, 1);
         if (g.launch(s, h)) return fail("S5 gemm launch failed");
         hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
-                           w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n, h2n16);
+                           w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n, h2n16, isc);
         // the gate logits (z_g, log_softmax([z_g, zsum]), step :185-188) are nobody's input before the selection: the
         // vocabulary kernel's row blocks compute them on the side instead of a launch of their own
         // (att_ga has a quarter of LSTM2's K: fewer stream-K pieces per tile, fewer slabs for the gate logits to add)
@@ -1214,8 +1259,8 @@ static int zero_state(vsr_handle* h, int M, hipStream_t s) {
     const size_t n = (size_t)M * h->d.rnn_size * sizeof(float);
     // the four state arrays of buffer 0 are consecutive in the workspace (carve): one memset
     HIPCHK(hipMemsetAsync(c.st[0][0], 0, (size_t)(reinterpret_cast<char*>(c.st[0][3]) - reinterpret_cast<char*>(c.st[0][0])) + n, s));
-    HIPCHK(hipMemsetAsync(c.st16[0][0], 0, (size_t)M * h->d.rnn_size * sizeof(uint16_t), s));     // bf16 images of the zero h1 / h2
-    HIPCHK(hipMemsetAsync(c.st16[0][1], 0, (size_t)M * h->d.rnn_size * sizeof(uint16_t), s));
+    HIPCHK(hipMemsetAsync(c.st16[0][0], 0, (size_t)M * h->d.rnn_size * 2 * sizeof(uint16_t), s));     // images of the zero h1 / h2 (bf16 or fp16 pairs)
+    HIPCHK(hipMemsetAsync(c.st16[0][1], 0, (size_t)M * h->d.rnn_size * 2 * sizeof(uint16_t), s));
     c.st16_ok[0] = true;
     c.st16_ok[1] = false;
     hipLaunchKernelGGL(k_init_rows, dim3(cdiv(M, 256)), dim3(256), 0, s, c.slot[0], c.word[0], h->d.bos_idx, M);
