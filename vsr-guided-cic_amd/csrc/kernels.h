@@ -357,7 +357,8 @@ __global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__
                         long long stride_b, const float* __restrict__ gpre, const float* __restrict__ c1n,
                         const float* __restrict__ b_sfc, int M, int H, int A, int D, float* __restrict__ g_t,
                         float* __restrict__ hA, float* __restrict__ sent, float* __restrict__ sa,
-                        float* __restrict__ gates6 /* optional (M,6H): column block 5 receives the shift gate */) {
+                        float* __restrict__ gates6 /* optional (M,6H): column block 5 receives the shift gate */,
+                        uint16_t* __restrict__ g_t16 = nullptr /* optional image of g_t (img_store) */, float isc = 0.f) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int W = H + A + D + A;
     if (i >= (long long)M * W) return;
@@ -367,7 +368,9 @@ __global__ void k_gate2(const float* __restrict__ c2a, const float* __restrict__
         if (c < H) {
             const long long o = (long long)row * H + c;
             const float gg = sigmoidf_(gpre[o] + s);
-            g_t[o] = gg * tanhf(c1n[o]);
+            const float gv = gg * tanhf(c1n[o]);
+            g_t[o] = gv;
+            if (g_t16) img_store(g_t16, o, gv, isc);
             if (gates6) gates6[(long long)row * 6 * H + 5LL * H + c] = gg;
         } else {
             hA[(long long)row * A + (c - H)] = s;

@@ -46,6 +46,9 @@ struct TrainCtx {
     std::vector<Img> imgs;
     size_t n_wT_imgs = 0;        // the first entries of imgs: the transposed weights
     float* h2img = nullptr;
+    // ... and the forward pass's A operands are written as fp16-pair images by their producers (kernels.h img_store; gemm_h2a.h takes them):
+    // h1 / h2 of every step (T + 1 slots like the fp32 saves), s_t / g_t / the attended vector of the current step
+    uint16_t *h1s16 = nullptr, *h2s16 = nullptr, *s_t16 = nullptr, *g_t16 = nullptr, *att16 = nullptr;
 };
 
 static inline size_t up4(size_t x) { return (x + 7) & ~size_t(7); }   // K paddings: multiples of 8 (16-byte bf16 chunks; fp32 needs 4)
@@ -118,6 +121,11 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
         img(t.tX_vbar, D * Bp, H2A_DET); img(t.tX_reg, D * RLp, H2A_REGION);
         b.off = (b.off + 255) & ~size_t(255);
         t.h2img = b.take<float>(off);
+        b.off = (b.off + 255) & ~size_t(255);
+        t.h1s16 = b.take<uint16_t>(2 * (T + 1) * B * H); t.h2s16 = b.take<uint16_t>(2 * (T + 1) * B * H);
+        t.s_t16 = b.take<uint16_t>(2 * B * H); t.g_t16 = b.take<uint16_t>(2 * B * H); t.att16 = b.take<uint16_t>(2 * B * D);
+    } else {
+        t.h1s16 = t.h2s16 = t.s_t16 = t.g_t16 = t.att16 = nullptr;
     }
     // GEMM slab scratch: 8 slabs of the largest product of the training path
     size_t big = std::max({4 * H * in1, V * H, 4 * H * in2, A * D, TB * H, TB * E, D * H, B * (in2 + 2 * H), H * in1, TB * V, TB * 6 * H});
@@ -237,6 +245,14 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     HIPCHK(hipMemsetAsync(t.c1s, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.h2s, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.c2s, 0, BH * sizeof(float), s));
+    // f16x2 flavour: fp16-pair images of the A operands (all-DMA kernel); BH elements of 4 bytes per state slot
+    const bool im = h->h2_on && !h->bf16_on && h->x3_on && h->h2_aimg && t.h1s16 && (B * H) % 8 == 0;
+    const float isc = im ? 32768.f : 0.f;                  // (2^15: the exponent of the unit-bounded class)
+    const int* att_exp = im ? h->h2_exps + H2A_ATT : nullptr;
+    if (im) {
+        HIPCHK(hipMemsetAsync(t.h1s16, 0, BH * 2 * sizeof(uint16_t), s));
+        HIPCHK(hipMemsetAsync(t.h2s16, 0, BH * 2 * sizeof(uint16_t), s));
+    }
     hipLaunchKernelGGL(k_train_indices, dim3(cdiv(TB, 256)), dim3(256), 0, s, word_in, slots, T, B, V, c.L, t.word32, t.slot32, t.rows_bt, c.nvalid_dev + 2);
     hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((long long)TB * E, 256)), dim3(256), 0, s, w.embed_weight, t.word32, TB, E, t.x_all);
     LAUNCHCHK();
@@ -246,7 +262,9 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         const int Nn[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
         for (int i = 0; i < 3; ++i) {
             GemmProb& p = g.prob(TB, Nn[i], t.scratch + off[i], 6 * H);
-            GemmBuilder::seg(p, t.x_all, E, nullptr, Wih[i] + xoff, in1, E, nullptr, H2A_EMBED);
+            // (with images: the rows are gathered from the embedding table's image by the GEMM itself)
+            if (im) GemmBuilder::seg(p, w.embed_weight, E, t.word32, Wih[i] + xoff, in1, E, nullptr, H2A_EMBED);
+            else GemmBuilder::seg(p, t.x_all, E, nullptr, Wih[i] + xoff, in1, E, nullptr, H2A_EMBED);
         }
         const int ns = g.finish(h);
         const long long stride = (long long)TB * 6 * H;
@@ -265,8 +283,10 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         float *s_t = t.s_ts + (size_t)tt * BH, *g_t = t.g_ts + (size_t)tt * BH;
         float *hA = t.hAs + (size_t)tt * B * A, *sa = t.sas + (size_t)tt * B * A, *ga = t.gas + (size_t)tt * B * A;
         float *sent = t.sents + (size_t)tt * B * D, *att = t.atts + (size_t)tt * B * D, *alpha = t.alphas + (size_t)tt * B * (c.R + 1);
-        const float* x = t.x_all + (size_t)tt * B * E;
         const int* slot = t.slot32 + (size_t)tt * B;
+        const uint16_t *h1o16 = im ? t.h1s16 + (size_t)tt * BH * 2 : nullptr, *h2o16 = im ? t.h2s16 + (size_t)tt * BH * 2 : nullptr;
+        uint16_t *h1n16 = im ? t.h1s16 + (size_t)(tt + 1) * BH * 2 : nullptr, *h2n16 = im ? t.h2s16 + (size_t)(tt + 1) * BH * 2 : nullptr;
+        uint16_t *s_t16 = im ? t.s_t16 : nullptr, *g_t16 = im ? t.g_t16 : nullptr, *att16 = im ? t.att16 : nullptr;
         {   // S1: the recurrent parts only (h2, h1 of the previous step); nothing to multiply at step 0
             int ns = 0;
             const long long stride = (long long)B * 6 * H;
@@ -278,8 +298,8 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
                 for (int i = 0; i < 3; ++i) {
                     if (!d.h2_first_lstm && !Whh[i]) continue;
                     GemmProb& p = g.prob(B, Nn[i], c.scratch + off[i], 6 * H);
-                    if (d.h2_first_lstm) GemmBuilder::seg(p, h2o, H, nullptr, Wih[i], in1, H, nullptr, H2A_UNIT);
-                    if (Whh[i]) GemmBuilder::seg(p, h1o, H, nullptr, Whh[i], H, H, nullptr, H2A_UNIT);
+                    if (d.h2_first_lstm) GemmBuilder::seg(p, h2o, H, nullptr, Wih[i], in1, H, h2o16, H2A_UNIT);
+                    if (Whh[i]) GemmBuilder::seg(p, h1o, H, nullptr, Whh[i], H, H, h1o16, H2A_UNIT);
                 }
                 ns = g.finish(h);
                 for (int i = 0; i < g.a.nprob; ++i) g.a.p[i].slab_stride = stride;
@@ -287,18 +307,18 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
             }
             hipLaunchKernelGGL(k_lstm1_train, dim3(cdiv((long long)B * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.vproj,
                                t.xproj_all + (size_t)tt * B * 6 * H, c1o, B, H, h1n, c1n, s_t, c.gpre, g1,
-                               d.h2_first_lstm ? 6 : 5 /* without h2 in the input the shift-gate block has no recurrent part */);
+                               d.h2_first_lstm ? 6 : 5 /* without h2 in the input the shift-gate block has no recurrent part */, h1n16, s_t16, isc);
         }
         {   // S2
             GemmBuilder g;
             GemmProb& p0 = g.prob(B, H, c.scratch, H + A);
-            GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H, nullptr, H2A_UNIT);
+            GemmBuilder::seg(p0, h1n, H, nullptr, w.W1_hg_weight, H, H, h1n16, H2A_UNIT);
             GemmProb& p1 = g.prob(B, A, c.scratch + H, H + A);
-            GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H, nullptr, H2A_UNIT);
+            GemmBuilder::seg(p1, h1n, H, nullptr, w.att_ha_weight, H, H, h1n16, H2A_UNIT);
             GemmProb& p2 = g.prob(B, D, nullptr, D + A);
-            GemmBuilder::seg(p2, s_t, H, nullptr, w.s_fc_weight, H, H, nullptr, H2A_UNIT);
+            GemmBuilder::seg(p2, s_t, H, nullptr, w.s_fc_weight, H, H, s_t16, H2A_UNIT);
             GemmProb& p3 = g.prob(B, A, nullptr, D + A);
-            GemmBuilder::seg(p3, s_t, H, nullptr, w.att_sa_weight, H, H, nullptr, H2A_UNIT);
+            GemmBuilder::seg(p3, s_t, H, nullptr, w.att_sa_weight, H, H, s_t16, H2A_UNIT);
             const int ns = g.finish(h);
             const long long stride_a = (long long)B * (H + A), stride_b = (long long)B * (D + A);
             float* c2b = c.scratch + stride_a * ns;
@@ -308,23 +328,23 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
             if (g.launch(s, h)) return fail("train S2 gemm launch failed");
             const long long n = (long long)B * (H + A + D + A);
             hipLaunchKernelGGL(k_gate2, dim3(cdiv(n, 256)), dim3(256), 0, s, c.scratch, c2b, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias,
-                               B, H, A, D, g_t, hA, sent, sa, g1);
+                               B, H, A, D, g_t, hA, sent, sa, g1, g_t16, isc);
         }
         {
             const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
             if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx, slot, 0, 1, B, c.L,
-                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
+                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha, att16, att_exp);
             else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx, slot, 0, 1, B, c.L,
-                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha);
+                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha, att16, att_exp);
         }
         {   // S5
             GemmBuilder g;
             GemmProb& p0 = g.prob(B, 4 * H, c.scratch, 4 * H);
-            GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H, nullptr, H2A_UNIT);
-            GemmBuilder::seg(p0, att, D, nullptr, w.lstm2_weight_ih + H, in2, D, nullptr, H2A_ATT);
-            if (tt > 0) GemmBuilder::seg(p0, h2o, H, nullptr, w.lstm2_weight_hh, H, H, nullptr, H2A_UNIT);
+            GemmBuilder::seg(p0, h1n, H, nullptr, w.lstm2_weight_ih, in2, H, h1n16, H2A_UNIT);
+            GemmBuilder::seg(p0, att, D, nullptr, w.lstm2_weight_ih + H, in2, D, att16, H2A_ATT);
+            if (tt > 0) GemmBuilder::seg(p0, h2o, H, nullptr, w.lstm2_weight_hh, H, H, h2o16, H2A_UNIT);
             GemmProb& p1 = g.prob(B, A, nullptr, A);
-            GemmBuilder::seg(p1, g_t, H, nullptr, w.att_ga_weight, H, H, nullptr, H2A_UNIT);
+            GemmBuilder::seg(p1, g_t, H, nullptr, w.att_ga_weight, H, H, g_t16, H2A_UNIT);
             const int ns = g.finish(h);
             const long long stride = (long long)B * 4 * H, stride_g = (long long)B * A;
             float* gas = c.scratch + stride * ns;
@@ -336,7 +356,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
             gl.ga_out = ga;
             const int gblocks = B;
             hipLaunchKernelGGL(k_fwd_tail, dim3(gblocks + cdiv((long long)B * H, 256)), dim3(256), 0, s, gl, gblocks, c.scratch, ns, stride,
-                               w.lstm2_bias_ih, w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, c2o, B, H, h2n, c2n, g2);
+                               w.lstm2_bias_ih, w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, c2o, B, H, h2n, c2n, g2, h2n16, isc);
         }
         LAUNCHCHK();
     }
@@ -344,7 +364,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         // (B, T, V) log-prob tensor is written row by row), then one log_softmax launch
         GemmBuilder g;
         GemmProb& p0 = g.prob(TB, V, t.scratch, V);
-        GemmBuilder::seg(p0, t.h2s, H, t.rows_bt, w.out_fc_weight, H, H, nullptr, H2A_UNIT);
+        GemmBuilder::seg(p0, t.h2s, H, t.rows_bt, w.out_fc_weight, H, H, im ? t.h2s16 : nullptr, H2A_UNIT);
         const int ns = g.finish(h);
         const long long stride = (long long)TB * V;
         if ((size_t)stride * ns > t.scratch_floats) return fail("training scratch too small for the vocabulary projection (%lld x %d)", stride, ns);

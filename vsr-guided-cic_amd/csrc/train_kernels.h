@@ -222,7 +222,8 @@ __global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long lo
                               const float* __restrict__ xproj /* (M, 6H) embedding part of this step, projected for all steps at once */,
                               const float* __restrict__ c1_old, int M, int H, float* __restrict__ h1n, float* __restrict__ c1n,
                               float* __restrict__ s_t, float* __restrict__ gpre, float* __restrict__ gates,
-                              int nblk /* column blocks (of 6) that the recurrent GEMM wrote */) {
+                              int nblk /* column blocks (of 6) that the recurrent GEMM wrote */,
+                              uint16_t* __restrict__ h1n16 = nullptr, uint16_t* __restrict__ s_t16 = nullptr /* optional images (img_store) */, float isc = 0.f) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
@@ -236,10 +237,12 @@ __global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long lo
     const float ig = sigmoidf_(q[0]), fg = sigmoidf_(q[1]), gg = tanhf(q[2]), og = sigmoidf_(q[3]), sg = sigmoidf_(q[4]);
     const float c = fg * c1_old[i] + ig * gg;
     const float tc = tanhf(c);
-    h1n[i] = og * tc;
+    const float h1v = og * tc, stv = sg * tc;
+    h1n[i] = h1v;
     c1n[i] = c;
-    s_t[i] = sg * tc;
+    s_t[i] = stv;
     gpre[i] = q[5];
+    if (h1n16) { img_store(h1n16, i, h1v, isc); img_store(s_t16, i, stv, isc); }
     gates[base] = ig; gates[base + H] = fg; gates[base + 2LL * H] = gg; gates[base + 3LL * H] = og; gates[base + 4LL * H] = sg;
 }
 
@@ -248,7 +251,8 @@ __global__ void k_lstm1_train(const float* __restrict__ pre, int nsplit, long lo
 __global__ __launch_bounds__(256) void k_fwd_tail(const GateLogitArgs gl, int gblocks,
                                                   const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ b_ih,
                                                   const float* __restrict__ b_hh, const float* __restrict__ vproj2, const float* __restrict__ c2_old,
-                                                  int M, int H, float* __restrict__ h2n, float* __restrict__ c2n, float* __restrict__ gates) {
+                                                  int M, int H, float* __restrict__ h2n, float* __restrict__ c2n, float* __restrict__ gates,
+                                                  uint16_t* __restrict__ h2n16 = nullptr /* optional image (img_store) */, float isc = 0.f) {
     if ((int)blockIdx.x < gblocks) {                      // one workgroup per row: every slab of a column in flight at once (a wave
         __shared__ float red[4];                          // per row walked the slabs in dependent rounds: 20 us at 8 slabs)
         gatelogit_block<256>(gl, blockIdx.x, red);
@@ -268,9 +272,11 @@ __global__ __launch_bounds__(256) void k_fwd_tail(const GateLogitArgs gl, int gb
     }
     const float ig = sigmoidf_(q[0]), fg = sigmoidf_(q[1]), gg = tanhf(q[2]), og = sigmoidf_(q[3]);
     const float c = fg * c2_old[i] + ig * gg;
-    h2n[i] = og * tanhf(c);
+    const float h2v = og * tanhf(c);
+    h2n[i] = h2v;
     c2n[i] = c;
     gates[base] = ig; gates[base + H] = fg; gates[base + 2LL * H] = gg; gates[base + 3LL * H] = og;
+    if (h2n16) img_store(h2n16, i, h2v, isc);
 }
 
 // ---------------------------------------------------------------------------------------------- backward
