@@ -71,6 +71,32 @@ def test_h2_xe_batch100_loss_and_gradient_norms():
     np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-3, atol=1e-8)
 
 
+@pytest.mark.parametrize("k", [-40, 30])
+def test_h2_backward_bounds_follow_the_gradients(k):
+    """the backward GEMMs scale their A operands - gradients - by bounds their producers measure on the device: an upstream gradient
+    scaled by 2^k moves every bound by k binades, every fp16 pair keeps its bits, and the 28 parameter gradients come out as EXACTLY
+    2^k times the unscaled ones (2^-40: a fixed scale would flush the fp16 terms to zero; 2^30: it would overflow them)."""
+    meta, _ = load_golden("g1_xe_b100")
+    cfg = meta["cfg"]
+    m, _ = _model(meta, gains=meta["gains"])
+    det, ctrl_seq, caps, gts = helpers.train_inputs(cfg, meta["seed"])
+    m.train()
+
+    def grads(scale):
+        m.zero_grad()
+        out, gate = m((det.to(DEV),), (caps.to(DEV), ctrl_seq.to(DEV)))
+        loss, _, _ = vo.xe_loss(out, gate, caps.to(DEV), gts.to(DEV))
+        (loss * scale).backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+    g1, gk = grads(1.0), grads(2.0 ** k)
+    for n in g1:
+        assert torch.isfinite(gk[n]).all(), n
+        ref = g1[n] * 2.0 ** k
+        big = ref.abs() > 2.0 ** -100                  # (fp32 subnormals of the scaled gradient round: not the GEMMs' doing)
+        assert torch.equal(gk[n][big], ref[big]), "%s: %d of %d elements differ" % (n, int((gk[n][big] != ref[big]).sum()), int(big.sum()))
+        assert float(g1[n].abs().max()) > 0
+
+
 def test_h2_sample_replay_500_rows():
     meta, g = load_golden("g9_scst_500")
     m, _ = _model(meta)

@@ -46,10 +46,10 @@ static void set_variant_globals(int tm) {
     g_h2a = tm == 5400;
 }
 
-static float* dev_rand(size_t n, unsigned seed) {
+static float* dev_rand(size_t n, unsigned seed, float amp = 1.f) {
     std::vector<float> h(n);
     unsigned s = seed * 2654435761u + 12345u;
-    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; }
+    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = amp * (((s >> 8) & 0xFFFF) / 65536.0f - 0.5f); }
     float* d;
     CK(hipMalloc(&d, (n + 8) * sizeof(float)));
     CK(hipMemset(d, 0, (n + 8) * sizeof(float)));
@@ -323,7 +323,7 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
         if (aligned) setenv("GEMM_PLAN_ALIGNED", rnd(0, 1) ? "8" : "2", 1); else unsetenv("GEMM_PLAN_ALIGNED");
         Builder b(slots, rnd(1, 8), tm, tn);
         const int nprob = rnd(1, 3);
-        struct Host { int M, N, ldc, coff; std::vector<std::vector<float>> A, W; std::vector<int> K, lda, ldw, woff; std::vector<std::vector<int>> idx; float* C; };
+        struct Host { int M, N, ldc, coff; std::vector<std::vector<float>> A, W; std::vector<int> K, lda, ldw, woff; std::vector<std::vector<int>> idx; float* C; double amp2k; };
         std::vector<Host> H(nprob);
         std::vector<void*> to_free;
         for (int p = 0; p < nprob; ++p) {
@@ -337,12 +337,17 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
             CK(hipMemset(h.C, 0, (size_t)8 * h.M * h.ldc * sizeof(float) + 64));
             GemmProb& gp = b.prob(h.M, h.N, h.C + h.coff, h.ldc);
             const int nseg = rnd(1, 3);
+            double amp2k = 0;
             for (int sg = 0; sg < nseg; ++sg) {
                 const int q = wide ? 8 : 4;
                 const int K = q * rnd(1, rnd(0, 3) ? 520 / q : 1600 / q);
                 const int rowsA = rnd(0, 1) ? h.M : h.M + rnd(1, 50);
                 const int lda = (g_a16 || g_h2a) ? K + 8 * rnd(0, 2) : K + 4 * rnd(0, 3), woff = q * rnd(0, 4), ldw = woff + K + q * rnd(0, 5);
-                float* A = dev_rand((size_t)rowsA * lda, seed * 131 + cs * 17 + p * 5 + sg); to_free.push_back(A);
+                // f16x2: the segments of a problem get operands of different magnitudes (different scale exponents: the accumulator units
+                // differ from segment to segment - gemm_h2a.h rescales, gemm_h2.h scales A per segment)
+                const float amp = g_h2 ? ldexpf(1.f, rnd(-6, 6)) : 1.f;
+                amp2k += (double)amp * amp * K;
+                float* A = dev_rand((size_t)rowsA * lda, seed * 131 + cs * 17 + p * 5 + sg, amp); to_free.push_back(A);
                 float* W = dev_rand((size_t)h.N * ldw + 64, seed * 137 + cs * 19 + p * 7 + sg); to_free.push_back(W);
                 std::vector<int> idx;
                 int* didx = nullptr;
@@ -358,6 +363,7 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
                 h.A.push_back(std::move(hA)); h.W.push_back(std::move(hW)); h.K.push_back(K); h.lda.push_back(lda); h.ldw.push_back(ldw); h.woff.push_back(woff);
                 h.idx.push_back(idx);
             }
+            h.amp2k = amp2k;
         }
         const int ns = b.finish();
         const bool tight = rnd(0, 1);                       // per-problem slab counts (gemm_tight_slabs): only those slabs are summed below
@@ -383,7 +389,7 @@ static int fuzz(int tm, int tn, int cases, unsigned seed) {
                     for (int q = 0; q < b.a.p[p].nslab; ++q) got += hC[(size_t)q * h.M * h.ldc + (size_t)i * h.ldc + h.coff + j];
                     worst = fmax(worst, fabs(got - ref));
                 }
-            scale = fmax(scale, sqrt((double)ktot) * 0.083);      // |a| |w| ~ U(-0.5, 0.5): products ~ 1/12 rms
+            scale = fmax(scale, sqrt(g_h2 ? h.amp2k : (double)ktot) * 0.083);      // |a| |w| ~ U(-0.5, 0.5) (x the segment's amplitude): products ~ 1/12 rms
             // the columns of the C window outside [coff, coff + N) must stay untouched (zero)
             for (int i = 0; i < h.M; ++i)
                 for (int j = 0; j < h.ldc; ++j)

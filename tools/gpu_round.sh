@@ -44,7 +44,12 @@ pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu --no-secondary --no-alt > $GRAFT_REPO_ROOT/$OUT/pmc_$c.log 2>&1)
   done
-  python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/gemm_f16x2_hbm_traffic.json gemm_nt_h2_kernel
+  python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/gemm_f16x2_hbm_traffic.json gemm_nt_h2a_kernel
+  # XE step: the same two passes over the training workload (the f16x2 kernels of its forward and backward GEMMs together)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmcxe_$c -- python3 $GRAFT_REPO_ROOT/bench.py --workload xe --steps 2 --warmup 1 --no-cpu > $GRAFT_REPO_ROOT/$OUT/pmcxe_$c.log 2>&1)
+  done
+  python tools/hbm_traffic.py $OUT/pmcxe_FETCH_SIZE $OUT/pmcxe_WRITE_SIZE $OUT/f16x2_xe_step_hbm_traffic.json gemm_nt_h2 "--workload xe --steps 2 --warmup 1 --no-cpu"
   python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/attend_hbm_traffic.json k_attend
   python tools/hbm_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/vocab_hbm_traffic.json k_vocab
   find $OUT -name "*kernel_trace.csv" -size +20M -delete ;;

@@ -115,6 +115,7 @@ struct vsr_handle {
     int h2_aligned_min = 4;
     // the producers of the decoder's A operands (h1, h2, s_t, g_t, the attended vector) write fp16-pair images next to the fp32 values
     // and launches whose A operands all have one take the all-DMA kernel (gemm_h2a.h); VSR_H2_AIMG=0: in-kernel split of fp32 A only
+    double aligned_eff_min = 0.75;    // wide launches: k-aligned pieces when they keep at least this share of the CUs busy, stream-K ranges otherwise (VSR_ALIGNED_EFF, percent)
     bool h2_aimg = true;
     int h2a_max_small = 128;          // launches of at most this many rows (and more than h2s_max) : 128 x 128 tiles of the all-DMA kernel
     std::vector<H2Range> h2t;         // the training pass's transposed operands (vsr_train_forward registers the images of its workspace)
@@ -400,7 +401,7 @@ struct GemmBuilder {
                         const int ns21 = gemm_plan_aligned(a21, slots, h->h2_aligned_min, 128, 128, H2_BK);
                         if (ns21 && aligned_eff(a21) >= 0.95 && (!ns22 || ns21 < ns22)) { a = a21; x3_tn = 1; return ns21; }
                     }
-                    if (ns22 && (force || aligned_eff(a22) >= 0.75)) { a = a22; x3_tn = 2; return ns22; }
+                    if (ns22 && (force || aligned_eff(a22) >= h->aligned_eff_min)) { a = a22; x3_tn = 2; return ns22; }
                 }
                 x3_tn = 2;
                 return gemm_plan(a, slots, 4, 128, 256, H2_BK);
@@ -457,7 +458,7 @@ struct GemmBuilder {
                         const int ns21 = gemm_plan_aligned(a21, slots, h->x3_aligned_min, 128, 128, X3_BK);
                         if (ns21 && aligned_eff(a21) >= 0.95 && (!ns22 || ns21 < ns22)) { a = a21; x3_tn = 1; return ns21; }
                     }
-                    if (ns22 && (force || aligned_eff(a22) >= 0.75)) { a = a22; x3_tn = 2; return ns22; }
+                    if (ns22 && (force || aligned_eff(a22) >= h->aligned_eff_min)) { a = a22; x3_tn = 2; return ns22; }
                 }
                 x3_tn = 2;
                 return gemm_plan(a, slots, 4, 128, 256, X3_BK);
@@ -574,6 +575,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_H2S_NS")) h->h2s_ns = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2_AIMG")) h->h2_aimg = atoi(e) != 0;
+    if (const char* e = getenv("VSR_ALIGNED_EFF")) h->aligned_eff_min = atoi(e) / 100.0;
     if (const char* e = getenv("VSR_X3S_SLOTS")) h->x3s_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_X3S_MIN")) h->x3s_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_X3_ALIGNED")) { h->x3_aligned_wide = atoi(e) / 10; h->x3_aligned_skinny = atoi(e) % 10; }
