@@ -122,14 +122,20 @@ int vsr_set_gemm_mode(vsr_handle* h, int32_t mode);
 
 /* ---- "f16x2": the fp32 flavour with three MFMAs per product and weights that are never split in a kernel (csrc/gemm_h2.h) ------
  * On top of mode 1.  vsr_refresh_h2_weights(h, buffer, ...) writes, into the caller's buffer (vsr_h2_weight_bytes, 256-byte aligned),
- * an fp16-PAIR image of each of the 14 weight matrices - x 2^e = hi + lo with hi = f16(x 2^e), lo = f16(x 2^e - hi), e chosen per
- * matrix from its max |x| so that nothing overflows, 4 bytes per element in the byte geometry of the fp32 matrix - plus the table of
- * scale exponents; vsr_prepare*() then also measures the bounds of the region / detection operands.  From then on every launch whose
- * W operands have images and whose A operands have a bound (all GEMMs of decoding and of the training FORWARD pass; the backward pass
- * multiplies gradients and keeps mode 1's kernels) forms a product as lo.hi + hi.lo + hi.hi on v_mfma_f32_*_f16 with fp32
- * accumulation, A being scaled and split inside the kernel.  Error against fp64 (tests/test_gpu_h2.py, next to the fma chain and f32x3):
- * the accumulation's, not the split's.  Call it again after every weight update (the images are not views); buffer = NULL: back to
- * mode 1 everywhere.  Sizes must be multiples of 8.  Turning it on or off voids what a change of mode voids. */
+ * an fp16-PAIR image of each of the 14 weight matrices and of the embedding table - x 2^e = hi + lo with hi = f16(x 2^e),
+ * lo = f16(x 2^e - hi), e chosen per tensor from its max |x| so that nothing overflows, 4 bytes per element in the byte geometry of the
+ * fp32 matrix - plus the table of scale exponents (4 KB at the head of the buffer; its second half is scratch the backward pass of
+ * training uses for the bounds of its gradient operands); vsr_prepare*() then also measures the bounds of the region / detection
+ * operands.  From then on every launch whose W operands have images and whose A operands have a bound - all GEMMs of decoding and of
+ * the training pass, forward and backward - forms a product as lo.hi + hi.lo + hi.hi on v_mfma_f32_*_f16 with fp32 accumulation.
+ * The decoder's own vectors (h1, h2, s_t, g_t, the attended vector) are written as fp16-pair images by the kernels that produce them
+ * and both operands go global -> LDS by DMA (csrc/gemm_h2a.h); a caller's fp32 tensors (vsr_prepare*(), a state handed to vsr_step)
+ * and the gradients of the backward pass are scaled and split inside the kernel (csrc/gemm_h2.h), the gradients by bounds the
+ * kernels that write them measure on the device.  Error against fp64 (tests/test_gpu_h2.py, next to the fma chain and f32x3): the
+ * accumulation's, not the split's.  Call it again after every weight update (the images are not views); buffer = NULL: back to
+ * mode 1 everywhere.  Sizes must be multiples of 8.  Turning it on or off voids what a change of mode voids.
+ * Environment (experiments): VSR_H2_AIMG=0 (no producer-written A images), VSR_H2S_MAX (rows up to which the weight-streaming kernel
+ * is used), VSR_ALIGNED_EFF (percent of busy CUs below which a wide launch takes stream-K ranges instead of k-aligned pieces). */
 size_t vsr_h2_weight_bytes(const vsr_handle* h);
 int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream);
 
