@@ -39,12 +39,10 @@ struct TrainCtx {
     // weight-gradient products) has a bf16 twin the transposing kernels write instead of the fp32 buffer
     struct Twin { const float* f; size_t n; uint16_t* b; };
     std::vector<Twin> twins;
-    // f16x2 flavour: the same operands have fp16-pair images (gemm_h2.h) in h2img, made from the fp32 buffers by ONE multi-tensor
-    // launch per group (transposed weights / transposed activations); slot = exponent slot of the values (the weight's own, or the
-    // class of the activation)
+    // f16x2 flavour: the same operands have fp16-pair images (gemm_h2.h) in h2img, written by the transposing kernel INSTEAD of the
+    // fp32 buffer (transpose()); slot = exponent slot of the values (the weight's own, or the class of the activation)
     struct Img { const float* f; size_t n; size_t off; int slot; };
     std::vector<Img> imgs;
-    size_t n_wT_imgs = 0;        // the first entries of imgs: the transposed weights
     float* h2img = nullptr;
     // ... and the forward pass's A operands are written as fp16-pair images by their producers (kernels.h img_store; gemm_h2a.h takes them):
     // h1 / h2 of every step (T + 1 slots like the fp32 saves), s_t / g_t / the attended vector of the current step
@@ -102,7 +100,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.tY_dpre1sum = b.take<float>(6 * H * Bp); t.tY_dpre2sum = b.take<float>(4 * H * Bp); t.tY_dP = b.take<float>(A * RLp);
     twin(t.tX_h2prev, H * TBp); twin(t.tX_x, E * TBp); twin(t.tX_h1prev, H * TBp); twin(t.tX_h1, H * TBp); twin(t.tX_att, D * TBp);
     twin(t.tX_st, H * TBp); twin(t.tX_gt, H * TBp); twin(t.tX_h2, H * TBp); twin(t.tX_vbar, D * Bp); twin(t.tX_reg, D * RLp);
-    t.imgs.clear(); t.n_wT_imgs = 0; t.h2img = nullptr;
+    t.imgs.clear(); t.h2img = nullptr;
     if (h->h2_on && !h->bf16_on) {
         size_t off = 0;
         auto img = [&](const float* f, size_t n, int slot) { t.imgs.push_back(TrainCtx::Img{f, n, off, slot}); off += up4(n); };
@@ -115,7 +113,6 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
         img(t.wT_ha, H * A, h->h2_slot_of(w.att_ha_weight)); img(t.wT_sfc, H * D, h->h2_slot_of(w.s_fc_weight));
         img(t.wT_sa, H * A, h->h2_slot_of(w.att_sa_weight)); img(t.wT_ga, H * A, h->h2_slot_of(w.att_ga_weight));
         img(t.wT_out, H * up4(V), h->h2_slot_of(w.out_fc_weight));
-        t.n_wT_imgs = t.imgs.size();
         img(t.tX_h2prev, H * TBp, H2A_UNIT); img(t.tX_x, E * TBp, H2A_EMBED); img(t.tX_h1prev, H * TBp, H2A_UNIT); img(t.tX_h1, H * TBp, H2A_UNIT);
         img(t.tX_att, D * TBp, H2A_ATT); img(t.tX_st, H * TBp, H2A_UNIT); img(t.tX_gt, H * TBp, H2A_UNIT); img(t.tX_h2, H * TBp, H2A_UNIT);
         img(t.tX_vbar, D * Bp, H2A_DET); img(t.tX_reg, D * RLp, H2A_REGION);
@@ -136,22 +133,6 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
 
 struct SegSpec { const float* A; int lda; const float* W; int ldw; int K; int a_cls = H2A_NONE; };
 
-// f16x2 flavour: fp16-pair images of imgs[i0, i1) from their fp32 buffers, one launch (n_override: elements of the LAST tensor actually in use)
-static void h2_images(vsr_handle* h, TrainCtx& t, hipStream_t s, size_t i0, size_t i1, long long n_last = -1) {
-    while (i0 < i1) {
-        H2Multi mc;
-        memset(&mc, 0, sizeof(mc));
-        int blocks = 0, k = 0;
-        for (; i0 < i1 && k < H2_MT; ++i0, ++k) {
-            const TrainCtx::Img& im = t.imgs[i0];
-            const long long n = (i0 + 1 == i1 && n_last >= 0) ? n_last : (long long)im.n;
-            mc.src[k] = im.f; mc.n[k] = (n + 7) & ~7LL; mc.dst_off[k] = (long long)im.off; mc.slot[k] = im.slot; mc.blk[k] = blocks;
-            blocks += (int)cdiv(mc.n[k], 8 * 256);
-        }
-        mc.blk[k] = blocks; mc.nt = k;
-        if (blocks > 0) hipLaunchKernelGGL(k_f32_to_h2_multi, dim3(blocks), dim3(256), 0, s, mc, reinterpret_cast<uint32_t*>(t.h2img), h->h2_exps);
-    }
-}
 // whole-pass bounds from the per-step ones (block 63: max over the steps; block 62 slots 2, 3: the sums over t of dpre1 / dpre2 rows)
 __global__ void k_h2_dyn_fold(int* __restrict__ dyn, int T) {
     const int j = threadIdx.x;
@@ -195,16 +176,22 @@ static void colsum(TrainCtx& t, hipStream_t s, const float* X, long long ld, int
     hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), COLSUM_CHUNKS), dim3(256), 0, s, X, ld, R, C, t.scratch);
     hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(C, 256)), dim3(256), 0, s, t.scratch, C, out);
 }
-// out = in^T (rows optionally gathered through `list`); in the bf16 mode a buffer with a registered bf16 twin (a GEMM W operand)
-// receives its bf16 image in the twin as well
+// out = in^T (rows optionally gathered through `list`).  A buffer that a GEMM takes as W receives ONLY its image - the registered bf16
+// twin in the bf16 mode, the fp16-pair image of the f16x2 flavour when the backward pass runs on those kernels (h2img) - and the fp32
+// buffer `out` then only lends its address
 static void transpose(vsr_handle* h, hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out,
-                      const int* list = nullptr) {
+                      const int* list = nullptr, bool h2img = false) {
     uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(out)) : nullptr;
     const dim3 grid(cdiv(C, 64), cdiv(R, 64)), block(256);
-    if (list && tw) hipLaunchKernelGGL((k_transpose_t<true, true>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, tw);
-    else if (list) hipLaunchKernelGGL((k_transpose_t<true, false>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, (uint16_t*)nullptr);
-    else if (tw) hipLaunchKernelGGL((k_transpose_t<false, true>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, tw);
-    else hipLaunchKernelGGL((k_transpose_t<false, false>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, (uint16_t*)nullptr);
+    const H2Range* r2 = (h2img && !tw) ? h->map_h2(out) : nullptr;
+    if (r2) {
+        uint16_t* img = reinterpret_cast<uint16_t*>(const_cast<float*>(r2->img + (out - r2->lo)));
+        if (list) hipLaunchKernelGGL((k_transpose_t<true, 2>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, img, h->h2_exps, r2->slot);
+        else hipLaunchKernelGGL((k_transpose_t<false, 2>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, img, h->h2_exps, r2->slot);
+    } else if (list && tw) hipLaunchKernelGGL((k_transpose_t<true, 1>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, tw);
+    else if (list) hipLaunchKernelGGL((k_transpose_t<true, 0>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, (uint16_t*)nullptr);
+    else if (tw) hipLaunchKernelGGL((k_transpose_t<false, 1>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, tw);
+    else hipLaunchKernelGGL((k_transpose_t<false, 0>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, (uint16_t*)nullptr);
 }
 
 extern "C" size_t vsr_train_workspace_bytes(const vsr_handle* h, int32_t B, int32_t T) {
@@ -443,37 +430,36 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     for (int i = 0; i < 28; ++i)
         if (!G[i]) return fail("vsr_train_backward: gradient pointer %d is null", i);
 
-    // ---- transposed weights (the optimizer may have changed them since the last call)
-    transpose(h, s, w.lstm1_weight_ih, in1, 4 * H, in1, t.wT_ih1, 4 * H);
-    transpose(h, s, w.W1_is_weight, in1, H, in1, t.wT_is, H);
-    transpose(h, s, w.W1_ig_weight, in1, H, in1, t.wT_ig, H);
-    transpose(h, s, w.lstm1_weight_hh, H, 4 * H, H, t.wT_hh1, 4 * H);
-    transpose(h, s, w.W1_hs_weight, H, H, H, t.wT_hs, H);
-    transpose(h, s, w.lstm2_weight_ih, in2, 4 * H, in2, t.wT_ih2, 4 * H);
-    transpose(h, s, w.lstm2_weight_hh, H, 4 * H, H, t.wT_hh2, 4 * H);
-    transpose(h, s, w.W1_hg_weight, H, H, H, t.wT_hg, H);
-    transpose(h, s, w.att_ha_weight, H, A, H, t.wT_ha, A);
-    transpose(h, s, w.s_fc_weight, H, D, H, t.wT_sfc, D);
-    transpose(h, s, w.att_sa_weight, H, A, H, t.wT_sa, A);
-    transpose(h, s, w.att_ga_weight, H, A, H, t.wT_ga, A);
-    const int Vp = (int)up4(V);        // K of the dh2_vocab GEMM must be a multiple of 8: zero-padded columns
-    if (Vp != V) {
-        HIPCHK(hipMemsetAsync(t.wT_out, 0, (size_t)H * Vp * sizeof(float), s));
-        if (uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(t.wT_out)) : nullptr) HIPCHK(hipMemsetAsync(tw, 0, (size_t)H * Vp * sizeof(uint16_t), s));
-    }
-    transpose(h, s, w.out_fc_weight, H, V, H, t.wT_out, Vp);
-    // f16x2 flavour: images of the transposed weights; the A operands of the backward GEMMs are gradients: their producers fold max |x|
-    // into "dynamic" slots of the exponent table (block tt of 8 slots for step tt, blocks 62 / 63 for the whole-pass operands)
+    // f16x2 flavour: the W operands of the backward GEMMs - transposed weights here, transposed activations in phase B - are written as
+    // fp16-pair images by the transposing kernel itself; the A operands are gradients: their producers fold max |x| into "dynamic" slots
+    // of the exponent table (block tt of 8 slots for step tt, blocks 62 / 63 for the whole-pass operands)
     const bool h2b = h->h2_on && !h->bf16_on && t.h2img && T <= 62;
     int* dyn = h2b ? h->h2_exps + H2_DYN0 : nullptr;
     enum { DY_dpre2, DY_dga, DY_dq, DY_dhA, DY_dsent, DY_dsa, DY_dpre1 };               // per-step block
     enum { DW_dlogits = 62 * 8, DW_dP, DW_dpre1sum, DW_dpre2sum, DW_step = 63 * 8 };      // whole-pass slots (DW_step + DY_x: max over the steps)
     auto dslot = [&](int i) { return h2b ? H2_DYN0 + i : (int)H2A_NONE; };
     auto dptr = [&](int i) { return h2b ? dyn + i : (int*)nullptr; };
-    if (h2b) {
-        HIPCHK(hipMemsetAsync(dyn, 0, H2_NDYN * sizeof(int), s));
-        h2_images(h, t, s, 0, t.n_wT_imgs);
+    if (h2b) HIPCHK(hipMemsetAsync(dyn, 0, H2_NDYN * sizeof(int), s));
+    // ---- transposed weights (the optimizer may have changed them since the last call)
+    transpose(h, s, w.lstm1_weight_ih, in1, 4 * H, in1, t.wT_ih1, 4 * H, nullptr, h2b);
+    transpose(h, s, w.W1_is_weight, in1, H, in1, t.wT_is, H, nullptr, h2b);
+    transpose(h, s, w.W1_ig_weight, in1, H, in1, t.wT_ig, H, nullptr, h2b);
+    transpose(h, s, w.lstm1_weight_hh, H, 4 * H, H, t.wT_hh1, 4 * H, nullptr, h2b);
+    transpose(h, s, w.W1_hs_weight, H, H, H, t.wT_hs, H, nullptr, h2b);
+    transpose(h, s, w.lstm2_weight_ih, in2, 4 * H, in2, t.wT_ih2, 4 * H, nullptr, h2b);
+    transpose(h, s, w.lstm2_weight_hh, H, 4 * H, H, t.wT_hh2, 4 * H, nullptr, h2b);
+    transpose(h, s, w.W1_hg_weight, H, H, H, t.wT_hg, H, nullptr, h2b);
+    transpose(h, s, w.att_ha_weight, H, A, H, t.wT_ha, A, nullptr, h2b);
+    transpose(h, s, w.s_fc_weight, H, D, H, t.wT_sfc, D, nullptr, h2b);
+    transpose(h, s, w.att_sa_weight, H, A, H, t.wT_sa, A, nullptr, h2b);
+    transpose(h, s, w.att_ga_weight, H, A, H, t.wT_ga, A, nullptr, h2b);
+    const int Vp = (int)up4(V);        // K of the dh2_vocab GEMM must be a multiple of 8: zero-padded columns
+    if (Vp != V) {
+        HIPCHK(hipMemsetAsync(t.wT_out, 0, (size_t)H * Vp * sizeof(float), s));
+        if (uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(t.wT_out)) : nullptr) HIPCHK(hipMemsetAsync(tw, 0, (size_t)H * Vp * sizeof(uint16_t), s));
+        if (const H2Range* r2 = h2b ? h->map_h2(t.wT_out) : nullptr) HIPCHK(hipMemsetAsync(const_cast<float*>(r2->img), 0, (size_t)H * Vp * sizeof(float), s));
     }
+    transpose(h, s, w.out_fc_weight, H, V, H, t.wT_out, Vp, nullptr, h2b);
     HIPCHK(hipMemsetAsync(t.dP, 0, (size_t)RL * A * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dh1_c, 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dh2_c, 0, BH * sizeof(float), s));
@@ -598,20 +584,17 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     const float* h1cur = t.h1s + BH;
     const float* h2prev = t.h2s;
     const float* h2cur = t.h2s + BH;
-    transpose(h, s, h2prev, H, TB, H, t.tX_h2prev, TBp);
-    transpose(h, s, t.x_all, E, TB, E, t.tX_x, TBp);
-    transpose(h, s, h1prev, H, TB, H, t.tX_h1prev, TBp);
-    transpose(h, s, h1cur, H, TB, H, t.tX_h1, TBp);
-    transpose(h, s, t.atts, D, TB, D, t.tX_att, TBp);
-    transpose(h, s, t.s_ts, H, TB, H, t.tX_st, TBp);
-    transpose(h, s, t.g_ts, H, TB, H, t.tX_gt, TBp);
-    transpose(h, s, h2cur, H, TB, H, t.tX_h2, TBp);
-    transpose(h, s, c.vbar, D, B, D, t.tX_vbar, Bp);
-    if (NV > 0) transpose(h, s, c.regions, (long long)D, NV, D, t.tX_reg, (long long)NVp, c.vlist);
-    if (h2b) {
-        h2_images(h, t, s, t.n_wT_imgs, t.imgs.size(), NV > 0 ? (long long)D * NVp : 0);      // (tX_reg is the last one: D x NVp in use)
-        hipLaunchKernelGGL(k_h2_dyn_fold, dim3(1), dim3(64), 0, s, dyn, T);
-    }
+    transpose(h, s, h2prev, H, TB, H, t.tX_h2prev, TBp, nullptr, h2b);
+    transpose(h, s, t.x_all, E, TB, E, t.tX_x, TBp, nullptr, h2b);
+    transpose(h, s, h1prev, H, TB, H, t.tX_h1prev, TBp, nullptr, h2b);
+    transpose(h, s, h1cur, H, TB, H, t.tX_h1, TBp, nullptr, h2b);
+    transpose(h, s, t.atts, D, TB, D, t.tX_att, TBp, nullptr, h2b);
+    transpose(h, s, t.s_ts, H, TB, H, t.tX_st, TBp, nullptr, h2b);
+    transpose(h, s, t.g_ts, H, TB, H, t.tX_gt, TBp, nullptr, h2b);
+    transpose(h, s, h2cur, H, TB, H, t.tX_h2, TBp, nullptr, h2b);
+    transpose(h, s, c.vbar, D, B, D, t.tX_vbar, Bp, nullptr, h2b);
+    if (NV > 0) transpose(h, s, c.regions, (long long)D, NV, D, t.tX_reg, (long long)NVp, c.vlist, h2b);
+    if (h2b) hipLaunchKernelGGL(k_h2_dyn_fold, dim3(1), dim3(64), 0, s, dyn, T);
     const int sP1 = dslot(DW_step + DY_dpre1), sQ = dslot(DW_step + DY_dq), sP2 = dslot(DW_step + DY_dpre2);
     transpose(h, s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp);
     transpose(h, s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp);

@@ -51,9 +51,14 @@ __device__ __forceinline__ void block_absmax_to(float m, int* bm) {
     block_absmax_to<1>(mm, bb);
 }
 
-template <bool GATHER, bool BF16>
+// IMG = 2: ONLY the f16x2 flavour's fp16-pair image (kernels.h: img_store, scaled by 2^exps[slot]) is written, to out16 (2-byte units of a
+// 4-byte-per-element buffer) - the W operands of the backward pass's GEMMs when they run on the f16x2 kernels (train.inc.h: transpose()).
+template <bool GATHER, int IMG>
 __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int R, int C,
-                                                     float* __restrict__ out, long long ld_out, uint16_t* __restrict__ out16) {
+                                                     float* __restrict__ out, long long ld_out, uint16_t* __restrict__ out16,
+                                                     const int* __restrict__ exps = nullptr, int slot = 0) {
+    constexpr bool BF16 = IMG != 0;            // (either image kind: the fp32 buffer is not written)
+    const float isc = IMG == 2 ? __int_as_float((127 + exps[slot]) << 23) : 0.f;
     __shared__ float t[64][65];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int q = threadIdx.x & 15, p = threadIdx.x >> 4;              // 16 lanes x 4 floats cover 64 columns; 16 rows per pass
@@ -85,10 +90,7 @@ __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ i
             float* dst = out + (long long)c * ld_out + r;
             if (vout && r + 3 < R) {
                 if (BF16) {
-                    uint2 o;
-                    o.x = (uint32_t)to_bf16_bits(v[0]) | ((uint32_t)to_bf16_bits(v[1]) << 16);
-                    o.y = (uint32_t)to_bf16_bits(v[2]) | ((uint32_t)to_bf16_bits(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(out16 + (long long)c * ld_out + r) = o;
+                    img_store4(out16, (long long)c * ld_out + r, make_float4(v[0], v[1], v[2], v[3]), isc);
                 } else {
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 }
@@ -97,10 +99,10 @@ __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ i
                 // instead of a memset of the whole transposed region per step)
                 for (int e = 0; e < 4; ++e)
                     if (r + e < R) {
-                        if (BF16) out16[(long long)c * ld_out + r + e] = to_bf16_bits(v[e]);
+                        if (BF16) img_store(out16, (long long)c * ld_out + r + e, v[e], isc);
                         else dst[e] = v[e];
                     } else if (r + e < ld_out) {
-                        if (BF16) out16[(long long)c * ld_out + r + e] = 0;
+                        if (BF16) img_store(out16, (long long)c * ld_out + r + e, 0.f, isc);
                         else dst[e] = 0.f;
                     }
             }
