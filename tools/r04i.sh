@@ -1,6 +1,6 @@
 #!/bin/bash
 # backward pass on the f16x2 kernels: gradient tests first (gate), then the XE step timed beside the f32x3 backward
-OUT=gpurun_out/r04v; mkdir -p $OUT
+OUT=gpurun_out/r04w; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_indexed.py tests/test_gpu_h2.py tests/test_gpu_ssp.py -m gpu -x -q 2>&1 | tail -15 > $OUT/tests.txt
 cat $OUT/tests.txt

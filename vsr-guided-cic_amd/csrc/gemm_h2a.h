@@ -196,7 +196,8 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
                     const long long row = S.a_idx ? (long long)S.a_idx[m] : (long long)m;
                     pa[i] = S.A + row * S.lda + wboff;
                 }
-                seg_exp = args.exps[S.exp_idx & 0xffff] + args.exps[S.exp_idx >> 16];
+                const int ia = S.exp_idx >> 16, va = args.exps[ia];           // (a dynamic slot holds the bound itself: gemm_h2.h h2_prob_exp)
+                seg_exp = args.exps[S.exp_idx & 0xffff] + (ia >= H2_DYN0 ? h2_exp_of(__int_as_float(va)) : va);
                 cw.fresh = false;
             }
             const bool in = cw.k + wg8 < cw.K;             // K is a multiple of 8: a group is inside or outside as a whole

@@ -131,7 +131,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     return (b.off + 255) & ~size_t(255);
 }
 
-struct SegSpec { const float* A; int lda; const float* W; int ldw; int K; int a_cls = H2A_NONE; };
+struct SegSpec { const float* A; int lda; const float* W; int ldw; int K; int a_cls = H2A_NONE; const uint16_t* A16 = nullptr; };
 
 // whole-pass bounds from the per-step ones (block 63: max over the steps; block 62 slots 2, 3: the sums over t of dpre1 / dpre2 rows)
 __global__ void k_h2_dyn_fold(int* __restrict__ dyn, int T) {
@@ -145,6 +145,7 @@ __global__ void k_h2_dyn_fold(int* __restrict__ dyn, int T) {
         int m2 = 0;
         for (int tt = 0; tt < T; ++tt) m2 = max(m2, dyn[tt * 8 + 2]);
         dyn[62 * 8 + 2] = __float_as_int(fmaxf(__int_as_float(m), __int_as_float(m2)) * (float)T);
+        dyn[62 * 8 + 4] = max(m, m2);                                       // all six column blocks of dpre1 (its transpose is one image)
     }
 }
 
@@ -152,8 +153,11 @@ __global__ void k_h2_dyn_fold(int* __restrict__ dyn, int T) {
 static int gemm_to(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, const SegSpec* segs, int nseg, float* dst, long long ldd) {
     GemmBuilder g;
     GemmProb& p = g.prob(M, N, t.scratch, N);
-    for (int i = 0; i < nseg; ++i) GemmBuilder::seg(p, segs[i].A, segs[i].lda, nullptr, segs[i].W, segs[i].ldw, segs[i].K, nullptr, segs[i].a_cls);
+    for (int i = 0; i < nseg; ++i) GemmBuilder::seg(p, segs[i].A, segs[i].lda, nullptr, segs[i].W, segs[i].ldw, segs[i].K, segs[i].A16, segs[i].a_cls);
+    for (int i = 0; i < nseg; ++i) g.a_image_only = g.a_image_only || (segs[i].A16 && !h->bf16_on);
     const int ns = g.finish(h);
+    for (int i = 0; i < nseg; ++i)
+        if (segs[i].A16 && !h->bf16_on && g.big != 37) return fail("training gemm: an A operand exists only as an fp16-pair image but the launch did not take the all-DMA kernel");
     const long long stride = (long long)M * N;
     if (ns == 1) {                          // every tile is produced by one workgroup: it writes the destination window itself
         g.a.p[0].C = dst; g.a.p[0].ldc = (int)ldd; g.a.p[0].slab_stride = 0;
@@ -167,8 +171,9 @@ static int gemm_to(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, cons
     return 0;
 }
 static int gemm_to1(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, int K, const float* A, int lda, const float* W, int ldw,
-                    float* dst, long long ldd, int a_cls = H2A_NONE) {
-    SegSpec sg{A, lda, W, ldw, K, a_cls};
+                    float* dst, long long ldd, int a_cls = H2A_NONE, bool a_is_image = false) {
+    // a_is_image: A is a transposed gradient that transpose() wrote as an fp16-pair image IN PLACE of the fp32 values (f16x2 flavour)
+    SegSpec sg{A, lda, W, ldw, K, a_cls, a_is_image ? reinterpret_cast<const uint16_t*>(A) : nullptr};
     return gemm_to(h, t, s, M, N, &sg, 1, dst, ldd);
 }
 // deterministic two-stage column sum through the (idle) slab scratch
@@ -179,12 +184,17 @@ static void colsum(TrainCtx& t, hipStream_t s, const float* X, long long ld, int
 // out = in^T (rows optionally gathered through `list`).  A buffer that a GEMM takes as W receives ONLY its image - the registered bf16
 // twin in the bf16 mode, the fp16-pair image of the f16x2 flavour when the backward pass runs on those kernels (h2img) - and the fp32
 // buffer `out` then only lends its address
+// self_slot >= 0: `out` itself receives the image (an A operand: a transposed gradient, scaled by the bound in that slot of the table)
 static void transpose(vsr_handle* h, hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out,
-                      const int* list = nullptr, bool h2img = false) {
+                      const int* list = nullptr, bool h2img = false, int self_slot = -1) {
     uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(out)) : nullptr;
     const dim3 grid(cdiv(C, 64), cdiv(R, 64)), block(256);
     const H2Range* r2 = (h2img && !tw) ? h->map_h2(out) : nullptr;
-    if (r2) {
+    if (h2img && !tw && !r2 && self_slot >= 0 && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 31) == 0) {
+        uint16_t* img = reinterpret_cast<uint16_t*>(out);
+        if (list) hipLaunchKernelGGL((k_transpose_t<true, 2>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, img, h->h2_exps, self_slot);
+        else hipLaunchKernelGGL((k_transpose_t<false, 2>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, img, h->h2_exps, self_slot);
+    } else if (r2) {
         uint16_t* img = reinterpret_cast<uint16_t*>(const_cast<float*>(r2->img + (out - r2->lo)));
         if (list) hipLaunchKernelGGL((k_transpose_t<true, 2>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, img, h->h2_exps, r2->slot);
         else hipLaunchKernelGGL((k_transpose_t<false, 2>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, img, h->h2_exps, r2->slot);
@@ -436,7 +446,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     const bool h2b = h->h2_on && !h->bf16_on && t.h2img && T <= 62;
     int* dyn = h2b ? h->h2_exps + H2_DYN0 : nullptr;
     enum { DY_dpre2, DY_dga, DY_dq, DY_dhA, DY_dsent, DY_dsa, DY_dpre1 };               // per-step block
-    enum { DW_dlogits = 62 * 8, DW_dP, DW_dpre1sum, DW_dpre2sum, DW_step = 63 * 8 };      // whole-pass slots (DW_step + DY_x: max over the steps)
+    enum { DW_dlogits = 62 * 8, DW_dP, DW_dpre1sum, DW_dpre2sum, DW_dpre1all, DW_step = 63 * 8 };      // whole-pass slots (DW_step + DY_x: max over the steps)
     auto dslot = [&](int i) { return h2b ? H2_DYN0 + i : (int)H2A_NONE; };
     auto dptr = [&](int i) { return h2b ? dyn + i : (int*)nullptr; };
     if (h2b) HIPCHK(hipMemsetAsync(dyn, 0, H2_NDYN * sizeof(int), s));
@@ -596,13 +606,17 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     if (NV > 0) transpose(h, s, c.regions, (long long)D, NV, D, t.tX_reg, (long long)NVp, c.vlist, h2b);
     if (h2b) hipLaunchKernelGGL(k_h2_dyn_fold, dim3(1), dim3(64), 0, s, dyn, T);
     const int sP1 = dslot(DW_step + DY_dpre1), sQ = dslot(DW_step + DY_dq), sP2 = dslot(DW_step + DY_dpre2);
-    transpose(h, s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp);
-    transpose(h, s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp);
-    transpose(h, s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp);
-    transpose(h, s, t.dhA_all, A, TB, A, t.tY_dhA, TBp);
-    transpose(h, s, t.dsent_all, D, TB, D, t.tY_dsent, TBp);
-    transpose(h, s, t.dsa_all, A, TB, A, t.tY_dsa, TBp);
-    transpose(h, s, t.dga_all, A, TB, A, t.tY_dga, TBp);
+    // the transposed gradients are the A operands of the weight-gradient GEMMs: with the whole-pass bounds known (k_h2_dyn_fold) they are
+    // written as fp16-pair images IN PLACE of the fp32 values and those GEMMs take the all-DMA kernel (tyi: the buffer holds an image)
+    const bool tyi = h2b && h->h2_aimg && TBp % 8 == 0 && (reinterpret_cast<uintptr_t>(t.tY_dpre1) & 255) == 0;     // (every buffer of the workspace shares that alignment)
+    const int sY1 = dslot(DW_dpre1all);
+    transpose(h, s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp, nullptr, tyi, sY1);
+    transpose(h, s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp, nullptr, tyi, sP2);
+    transpose(h, s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp, nullptr, tyi, dslot(DW_dlogits));
+    transpose(h, s, t.dhA_all, A, TB, A, t.tY_dhA, TBp, nullptr, tyi, dslot(DW_step + DY_dhA));
+    transpose(h, s, t.dsent_all, D, TB, D, t.tY_dsent, TBp, nullptr, tyi, dslot(DW_step + DY_dsent));
+    transpose(h, s, t.dsa_all, A, TB, A, t.tY_dsa, TBp, nullptr, tyi, dslot(DW_step + DY_dsa));
+    transpose(h, s, t.dga_all, A, TB, A, t.tY_dga, TBp, nullptr, tyi, dslot(DW_step + DY_dga));
     const float* dP_rows = t.dP;
     if (c.ridx) {
         // index lists: several slot entries of an image name the same bank row; att_va's gradient runs over bank rows, so the
@@ -610,11 +624,12 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         hipLaunchKernelGGL(k_dP_to_bank, dim3(c.n_img * c.Rb), dim3(128), 0, s, t.dP, c.ridx, c.L * c.R, c.Rb, A, t.dP_bank);
         dP_rows = t.dP_bank;
     }
-    if (NV > 0) transpose(h, s, dP_rows, (long long)A, NV, A, t.tY_dP, (long long)NVp, c.vlist);
     if (h2b && NV > 0) {
         const long long ndp = (long long)(c.ridx ? (size_t)c.n_img * c.Rb : (size_t)RL) * A;
         hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<long long>(1024, cdiv(ndp, 1024))), dim3(256), 0, s, dP_rows, ndp, reinterpret_cast<unsigned*>(dyn + DW_dP));
     }
+    const bool tyiP = tyi && NVp % 8 == 0;
+    if (NV > 0) transpose(h, s, dP_rows, (long long)A, NV, A, t.tY_dP, (long long)NVp, c.vlist, tyiP, dslot(DW_dP));
     hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 6 * H, 256)), dim3(256), 0, s, t.dpre1, T, (long long)B * 6 * H, t.dpre1sum);
     transpose(h, s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
     LAUNCHCHK();
@@ -630,27 +645,27 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         const int r0[3] = {0, 4 * H, 5 * H}, nr[3] = {4 * H, H, H};
         for (int i = 0; i < 3; ++i) {
             const float* dy = t.tY_dpre1 + (size_t)r0[i] * TBp;
-            const int sa = i == 2 ? sQ : sP1;
-            if (d.h2_first_lstm && gemm_to1(h, t, s, nr[i], H, TBp, dy, TBp, t.tX_h2prev, TBp, Gw[i], in1, sa)) return 1;
+            const int sa = tyi ? sY1 : (i == 2 ? sQ : sP1);
+            if (d.h2_first_lstm && gemm_to1(h, t, s, nr[i], H, TBp, dy, TBp, t.tX_h2prev, TBp, Gw[i], in1, sa, tyi)) return 1;
             if (gemm_to1(h, t, s, nr[i], D, Bp, t.tY_dpre1sum + (size_t)r0[i] * Bp, Bp, t.tX_vbar, Bp, Gw[i] + voff, in1, dslot(DW_dpre1sum))) return 1;
-            if (gemm_to1(h, t, s, nr[i], E, TBp, dy, TBp, t.tX_x, TBp, Gw[i] + xoff, in1, sa)) return 1;
+            if (gemm_to1(h, t, s, nr[i], E, TBp, dy, TBp, t.tX_x, TBp, Gw[i] + xoff, in1, sa, tyi)) return 1;
         }
     }
     HIPCHK(hipEventRecord(t.bucket_ev[0], s));
     // ---- bucket 1: lstm_cell_2
-    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2, sP2)) return 1;
-    if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2, sP2)) return 1;
+    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2, sP2, tyi)) return 1;
+    if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2, sP2, tyi)) return 1;
     if (d.img_second_lstm) {
         hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 4 * H, 256)), dim3(256), 0, s, t.dpre2, T, (long long)B * 4 * H, t.dpre2sum);
         transpose(h, s, t.dpre2sum, 4 * H, B, 4 * H, t.tY_dpre2sum, Bp);
         if (gemm_to1(h, t, s, 4 * H, D, Bp, t.tY_dpre2sum, Bp, t.tX_vbar, Bp, G[g_Wih2] + H + D, in2, dslot(DW_dpre2sum))) return 1;
     }
-    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H, sP2)) return 1;
+    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H, sP2, tyi)) return 1;
     colsum(t, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2]);
     HIPCHK(hipMemcpyAsync(G[g_bhh2], G[g_bih2], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipEventRecord(t.bucket_ev[1], s));
     // ---- bucket 2: out_fc and the embedding
-    if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H, dslot(DW_dlogits))) return 1;
+    if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H, dslot(DW_dlogits), tyi)) return 1;
     colsum(t, s, t.dlogits, (long long)Vp, TB, V, G[g_bout]);
     {   // embedding: dx = dpre1 . [W_ih1 ; W_is ; W_ig][:, x columns], summed onto the rows that were looked up (ordered, no atomics)
         SegSpec sg[3] = {{t.dpre1, 6 * H, t.wT_ih1 + (size_t)xoff * 4 * H, 4 * H, 4 * H, sP1},
@@ -662,28 +677,28 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     }
     HIPCHK(hipEventRecord(t.bucket_ev[2], s));
     // ---- bucket 3: the recurrent LSTM1 / sentinel-gate weights, all LSTM1 / gate biases, s_fc, att_va
-    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H, sP1)) return 1;
-    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H, sP1)) return 1;
+    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H, tyi ? sY1 : sP1, tyi)) return 1;
+    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H, tyi ? sY1 : sP1, tyi)) return 1;
     colsum(t, s, t.dpre1, (long long)6 * H, TB, 4 * H, G[g_bih1]);
     HIPCHK(hipMemcpyAsync(G[g_bhh1], G[g_bih1], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
     colsum(t, s, t.dpre1 + 4 * H, (long long)6 * H, TB, H, G[g_bis]);
     HIPCHK(hipMemcpyAsync(G[g_bhs], G[g_bis], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
     colsum(t, s, t.dpre1 + 5 * H, (long long)6 * H, TB, H, G[g_big]);
     HIPCHK(hipMemcpyAsync(G[g_bhg], G[g_big], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (gemm_to1(h, t, s, D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H, dslot(DW_step + DY_dsent))) return 1;
+    if (gemm_to1(h, t, s, D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H, dslot(DW_step + DY_dsent), tyi)) return 1;
     colsum(t, s, t.dsent_all, (long long)D, TB, D, G[g_bsfc]);
     // att_va: dP^T (A, NV) x regions^T (D, NV) over the non-padding rows
     if (NV > 0) {
-        if (gemm_to1(h, t, s, A, D, NVp, t.tY_dP, NVp, t.tX_reg, NVp, G[g_Wva], D, dslot(DW_dP))) return 1;
+        if (gemm_to1(h, t, s, A, D, NVp, t.tY_dP, NVp, t.tX_reg, NVp, G[g_Wva], D, dslot(DW_dP), tyiP)) return 1;
     } else {
         HIPCHK(hipMemsetAsync(G[g_Wva], 0, (size_t)A * D * sizeof(float), s));
     }
     HIPCHK(hipEventRecord(t.bucket_ev[3], s));
     // ---- bucket 4 (the tail, 3.5 M floats): W1_hg, att_ha, att_sa, att_ga and the three score vectors
-    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H, sQ)) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H, dslot(DW_step + DY_dhA))) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H, dslot(DW_step + DY_dsa))) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H, dslot(DW_step + DY_dga))) return 1;
+    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H, tyi ? sY1 : sQ, tyi)) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H, dslot(DW_step + DY_dhA), tyi)) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H, dslot(DW_step + DY_dsa), tyi)) return 1;
+    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H, dslot(DW_step + DY_dga), tyi)) return 1;
     colsum(t, s, t.dwa_rows, (long long)A, TB, A, G[g_wa]);
     colsum(t, s, t.dws_rows, (long long)A, TB, A, G[g_ws]);
     colsum(t, s, t.dwg_rows, (long long)A, TB, A, G[g_wg]);

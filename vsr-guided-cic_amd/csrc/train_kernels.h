@@ -58,7 +58,11 @@ __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ i
                                                      float* __restrict__ out, long long ld_out, uint16_t* __restrict__ out16,
                                                      const int* __restrict__ exps = nullptr, int slot = 0) {
     constexpr bool BF16 = IMG != 0;            // (either image kind: the fp32 buffer is not written)
-    const float isc = IMG == 2 ? __int_as_float((127 + exps[slot]) << 23) : 0.f;
+    float isc = 0.f;
+    if constexpr (IMG == 2) {                   // (slots from H2_DYN0 up hold the measured BOUND of a gradient operand, not its exponent: gemm_h2.h)
+        const int ev = exps[slot];
+        isc = h2_pow2(slot >= H2_DYN0 ? h2_exp_of(__int_as_float(ev)) : ev);
+    }
     __shared__ float t[64][65];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
     const int q = threadIdx.x & 15, p = threadIdx.x >> 4;              // 16 lanes x 4 floats cover 64 columns; 16 rows per pass

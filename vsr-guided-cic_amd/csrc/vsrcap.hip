@@ -293,6 +293,7 @@ struct GemmBuilder {
     bool a16_all = false;   // bf16 kernel: every segment's A operand has a bf16 image (GemmSeg::A16)
     bool keep_fp32 = false; // bf16 mode: this launch stays fp32-equivalent (f32x3 kernels): the hoisted att_va(regions) projection, whose
                             // outputs are summed RAW over up to 36 rows into the shift logit (step :187) - bf16 rounding adds up coherently there
+    bool a_image_only = false;   // f16x2 flavour: an A operand exists ONLY as an fp16-pair image (GemmSeg::A16; the training pass's transposed gradients): the launch must take the all-DMA kernel
     bool stale_w = false;   // bf16 mode: a W operand exists only as a bf16 image but the launch does not qualify for the bf16 kernel
     // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
     int finish(const vsr_handle* h) {
@@ -374,7 +375,7 @@ struct GemmBuilder {
                         }
                 };
                 const int slots = h->gemm_slots_bf16;
-                if (maxM <= h->h2s_max && maxM <= 128) {
+                if (maxM <= h->h2s_max && maxM <= 128 && !(a_image_only && aimg)) {
                     GemmArgs as = ah;
                     if (const int ns = gemm_plan_aligned(as, h->h2s_slots, h->h2s_min, 128, h2s_bn(h->h2s_ns), H2_BK)) { a = as; big = 36; x3s_mt = (maxM + 15) / 16; return ns; }
                 }
