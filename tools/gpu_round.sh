@@ -7,6 +7,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 for w in $WHAT; do
 case $w in
+smoke)
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log; tail -3 $OUT/smoke.log ;;
 tests)
   timeout 1500 python -m pytest tests -m gpu -q -rA --durations=15 > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -40 $OUT/pytest.log ;;
 bench)
