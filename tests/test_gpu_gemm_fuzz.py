@@ -17,7 +17,7 @@ TOOL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 
 @pytest.mark.parametrize("variant", ["1 1", "121 1", "2 2", "1605 2", "1607 2", "1664 1", "1665 1", "1664 21", "1665 21", "3300 1", "3300 21",
                                      "3400 1",           # the weight-streaming f32x3 kernel (<= 128 rows, k-aligned pieces only)
-                                     "5200 1", "5200 21", "5300 1", "5400 1", "5400 21"])
+                                     "5200 1", "5200 21", "5300 1", "5400 1", "5400 21", "1666 1", "1666 21"])
 def test_gemm_variant_on_random_ragged_launches(variant):
     if not os.path.exists(TOOL):
         pytest.skip("tools/gemm_bench not built (python vsr-guided-cic_amd/build.py --tool, or __graft_entry__.build())")

@@ -21,6 +21,7 @@
 #include "../vsr-guided-cic_amd/csrc/gemm_x3s.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_h2.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_h2a.h"
+#include "../vsr-guided-cic_amd/csrc/gemm_b16a.h"
 
 using namespace vsr;
 
@@ -40,8 +41,8 @@ static bool is_x3(int tm) { return tm == 3300; }
 static bool g_h2a = false;                     // variant 5400: the all-DMA wide kernel (gemm_h2a.h): A operands are images too
 static bool is_h2(int tm) { return tm == 5200 || tm == 5300 || tm == 5400; }
 static void set_variant_globals(int tm) {
-    g_bf16 = tm == 1664 || tm == 1665;
-    g_a16 = tm == 1665;
+    g_bf16 = tm == 1664 || tm == 1665 || tm == 1666;      // 1666: the all-DMA bf16 kernel (gemm_b16a.h), bf16 images of both operands
+    g_a16 = tm == 1665 || tm == 1666;
     g_h2 = is_h2(tm);
     g_h2a = tm == 5400;
 }
@@ -146,9 +147,9 @@ struct Builder {
             return ns;
         }
         if (tm > 1600 && tm <= 1608) { bm = 16 * (tm - 1600); bn = 64 * tn; }      // rows-16 kernel: tm = 1600 + TM, tn = TN
-        if (tm == 1664 || tm == 1665) { bm = 128; bn = tn == 21 ? 128 : 256; }       // bf16 throughput kernel (bf16 W twins; 1665: bf16 A images too); tn 21: 128 x 128 tile
+        if (tm == 1664 || tm == 1665 || tm == 1666) { bm = 128; bn = tn == 21 ? 128 : 256; }       // bf16 throughput kernel (bf16 W twins; 1665: bf16 A images too); tn 21: 128 x 128 tile
         int ns = 0;
-        const bool b16 = tm == 1664 || tm == 1665;
+        const bool b16 = tm == 1664 || tm == 1665 || tm == 1666;
         if ((b16 || is_x3(tm) || tm == 5200 || tm == 5400) && getenv("GEMM_PLAN_ALIGNED")) ns = gemm_plan_aligned(a, slots, atoi(getenv("GEMM_PLAN_ALIGNED")), bm, bn, b16 ? B16_BK : GEMM_BK);
         if (!ns) ns = gemm_plan(a, slots, min_iters, bm, bn, b16 ? B16_BK : GEMM_BK);
         for (int i = 0; i < a.nprob; ++i) a.p[i].slab_stride = (long long)a.p[i].M * a.p[i].ldc;
@@ -195,6 +196,8 @@ struct Builder {
         }
         else if (is_x3(tm) && tn == 21) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 1>), g, dim3(X3_THREADS), 0, st, a);
         else if (is_x3(tm)) hipLaunchKernelGGL((gemm_nt_x3_kernel<2, 2>), g, dim3(X3_THREADS), 0, st, a);
+        else if (tm == 1666 && tn == 21) hipLaunchKernelGGL((gemm_nt_b16a_kernel<2, 1>), g, dim3(B16_THREADS), 0, st, a);
+        else if (tm == 1666) hipLaunchKernelGGL((gemm_nt_b16a_kernel<2, 2>), g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 1664 && tn == 21) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 1>), g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 1665 && tn == 21) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<true, 1>), g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 1664) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<false, 2>), g, dim3(B16_THREADS), 0, st, a);

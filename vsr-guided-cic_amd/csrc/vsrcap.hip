@@ -30,6 +30,7 @@
 #include "gemm_x3s.h"
 #include "gemm_h2.h"
 #include "gemm_h2a.h"
+#include "gemm_b16a.h"
 #include "kernels.h"
 #include "train_kernels.h"
 
@@ -117,6 +118,7 @@ struct vsr_handle {
     // and launches whose A operands all have one take the all-DMA kernel (gemm_h2a.h); VSR_H2_AIMG=0: in-kernel split of fp32 A only
     double aligned_eff_min = 0.75;    // wide launches: k-aligned pieces when they keep at least this share of the CUs busy, stream-K ranges otherwise (VSR_ALIGNED_EFF, percent)
     bool h2_aimg = true;
+    bool b16_dma = true;              // bf16 mode: launches whose A operands all have bf16 images take the all-DMA kernel (VSR_B16_DMA=0: register-staged)
     int h2a_max_small = 128;          // launches of at most this many rows (and more than h2s_max) : 128 x 128 tiles of the all-DMA kernel
     std::vector<H2Range> h2t;         // the training pass's transposed operands (vsr_train_forward registers the images of its workspace)
     const H2Range* map_h2(const float* p) const {
@@ -325,7 +327,7 @@ struct GemmBuilder {
                         S.W = reinterpret_cast<const float*>(h->map16(S.W));
                         a16_all = a16_all && S.A16 && (S.lda % 8 == 0) && ((reinterpret_cast<uintptr_t>(S.A16) & 15) == 0);
                     }
-                big = 32;
+                big = (a16_all && h->b16_dma) ? 38 : 32;        // 38: both operands are images: the all-DMA kernel (gemm_b16a.h)
                 // launches whose rows fit one m-tile: 128 x 128 tiles (twice the tiles, half the k pieces per tile), as for f32x3
                 x3_tn = (h->x3_skinny && maxM <= 128) ? 1 : 2;
                 const int BN = x3_tn == 1 ? 128 : 256;
@@ -483,7 +485,7 @@ struct GemmBuilder {
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     if (stale_w) return fail("bf16 mode: a GEMM launch names a transposed operand that only exists as a bf16 image but cannot take the bf16 kernel (K / leading dimensions must be multiples of 8)");
-    dim3 grid(((a.G + 7) / 8) * 8), block(big == 32 ? B16_THREADS : (big == 33 || big == 35 || big == 37) ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34 / 36: 256 = X3S_THREADS = H2S_THREADS)
+    dim3 grid(((a.G + 7) / 8) * 8), block((big == 32 || big == 38) ? B16_THREADS : (big == 33 || big == 35 || big == 37) ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34 / 36: 256 = X3S_THREADS = H2S_THREADS)
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
     if (big == 36) {
@@ -493,7 +495,9 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
             default: if (h->h2s_ns == 2) hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 2>), grid, block, 0, s, a); else hipLaunchKernelGGL((gemm_nt_h2s_kernel<8, 1>), grid, block, 0, s, a); break;
         }
 #undef H2S_CASE
-    } else if (big == 37 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 2>), grid, block, 0, s, a);
+    } else if (big == 38 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_b16a_kernel<2, 2>), grid, block, 0, s, a);
+    else if (big == 38) hipLaunchKernelGGL((gemm_nt_b16a_kernel<2, 1>), grid, block, 0, s, a);
+    else if (big == 37 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 37) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1>), grid, block, 0, s, a);
     else if (big == 35 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 35) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 1>), grid, block, 0, s, a);
@@ -576,6 +580,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_H2S_NS")) h->h2s_ns = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2_AIMG")) h->h2_aimg = atoi(e) != 0;
+    if (const char* e = getenv("VSR_B16_DMA")) h->b16_dma = atoi(e) != 0;
     if (const char* e = getenv("VSR_ALIGNED_EFF")) h->aligned_eff_min = atoi(e) / 100.0;
     if (const char* e = getenv("VSR_X3S_SLOTS")) h->x3s_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_X3S_MIN")) h->x3s_min = std::max(1, atoi(e));
