@@ -252,7 +252,7 @@ def roofline_block(dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic=No
     if dtype == "bf16":
         # bf16 operands take the matrix pipe out of the picture (16x the fp32 rate): the GEMMs are bound by the bytes they move
         gbs = gemm_bytes / (gemm_ms * 1e-3) / 1e9 if gemm_ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": "gemm_nt_bf16w_kernel (v_mfma_f32_32x32x16_bf16; fp32 A converted on the way into LDS, bf16 W copies)",
+        return {"bound": "hbm", "kernel": "gemm_nt_b16a_kernel (v_mfma_f32_32x32x16_bf16; bf16 W copies and producer-written bf16 A images, both global -> LDS by DMA) and, for launches with an fp32-only A operand, gemm_nt_bf16w_kernel (A converted on the way into LDS)",
                 "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": gemm_bytes / max(gemm_n, 1), "launches": gemm_seen, "launches_timed": gemm_n,
                 "avg_launch_us": gemm_ms * 1e3 / max(gemm_n, 1), "gemm_share_of_wall": gemm_ms * 1e-3 / max(gemm_n, 1) * gemm_seen / dt,
