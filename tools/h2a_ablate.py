@@ -7,6 +7,7 @@ ten times slower), and tools/gemm_bench is built from it once per ablation as to
   3  ... both                                                        (no global traffic in the k loop)
   4  the multipliers skip their LDS reads and MFMAs                  (data movement and barriers only)
   5  the multipliers read LDS but issue no MFMA
+  6  no epilogue: the tile pieces are not staged and not stored (what do the LDS-staged 16-byte stores of 128 KB per workgroup cost?)
 usage: tools/h2a_ablate.py ; then tools/gemm_bench_abl<n> 500 256 4 5400 1"""
 import os, shutil, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,8 +39,10 @@ rep("#pragma unroll\n            for (int kk = 0; kk < BK / 16; ++kk) {\n       
     "            if constexpr (abl != 4)\n#pragma unroll\n            for (int kk = 0; kk < BK / 16; ++kk) {\n                const int wh")
 rep("                H2A_TERM(al, bh)\n                H2A_TERM(ah, bl)\n                H2A_TERM(ah, bh)\n",
     "                if constexpr (abl != 5) {\n                H2A_TERM(al, bh)\n                H2A_TERM(ah, bl)\n                H2A_TERM(ah, bh)\n                } else { asm volatile(\"\" :: \"v\"(ah[0]), \"v\"(al[0]), \"v\"(bh[0]), \"v\"(bl[0]), \"v\"(ah[TM - 1]), \"v\"(al[TM - 1]), \"v\"(bh[TN - 1]), \"v\"(bl[TN - 1])); }\n")
+rep("        wait_loads<0>();\n        __syncthreads();                                   // ... for every wave's requests: nothing lands in `stage` from here on\n",
+    "        wait_loads<0>();\n        __syncthreads();                                   // ... for every wave's requests: nothing lands in `stage` from here on\n        if constexpr (abl == 6) {\n            if constexpr (decltype(MULT)::value) {\n                _Pragma(\"unroll\") for (int ti = 0; ti < TM; ++ti) _Pragma(\"unroll\") for (int tj = 0; tj < TN; ++tj) _Pragma(\"unroll\") for (int e = 0; e < 16; ++e) asm volatile(\"\" :: \"v\"(acc[ti][tj][e]));\n            }\n            return;\n        }\n")
 open(p, "w").write(s)
 b = d + "/tools/gemm_bench.hip"
-procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-DH2A_ABL=%d" % n, "-o", ROOT + "/tools/gemm_bench_abl%d" % n, b]) for n in range(6)]
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-DH2A_ABL=%d" % n, "-o", ROOT + "/tools/gemm_bench_abl%d" % n, b]) for n in (0, 6)]
 assert all(p.wait() == 0 for p in procs)
-print("built tools/gemm_bench_abl0..5")
+print("built tools/gemm_bench_abl0, _abl6 (edit the tuple above for the others)")
