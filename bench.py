@@ -95,52 +95,46 @@ def cpu_info():
 def cpu_baseline(weights, sample_B, beam, torch, synth, full_B=0):
     """the CPU oracle (PyTorch CPU, fp32) on the same synthetic workload, in the reference's AS-WRITTEN
     op order (per-step recompute of the pooled descriptor / region projection, statics re-gather per beam step, full sort)
-    and HOISTED beside it.  torch.set_num_threads(physical cores).  Bounded sample: sample_B images, 1 warm-up call, median
-    of 3 timed calls each.  full_B > 0: additionally ONE as-written call at the workload's own batch size (M = 500 rows gives
-    the CPU's GEMMs better shapes than the sample's M = 60) - that call is then the `value` of record."""
+    and HOISTED beside it, torch.set_num_threads(physical cores).  Both flavours are timed the SAME way on the SAME inputs:
+    full_B > 0 (default): the GPU leg's own first batch (B = 100, M = 500 rows), one warm-up call, then 2 timed calls as written and
+    3 hoisted; `value` / `hoisted_value` = tokens/s at the MEDIAN call time, `*_best` at the fastest.  full_B = 0: a bounded sample
+    of sample_B images (1 warm-up on 2 images, median of 3)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vsr_oracle as vo
     c = CFG
     model, cores = cpu_info()
     torch.set_num_threads(cores)
-    det = torch.from_numpy(synth.make_detections(sample_B, c["R0"], c["D"], seed=77))
-    ctrl = torch.from_numpy(synth.make_ctrl(sample_B, c["L"], c["R"], c["D"], seed=77))
+    B = full_B if full_B > 0 else sample_B
+    seed = 1000 if full_B > 0 else 77                      # (1000 = the GPU leg's first batch)
+    det = torch.from_numpy(synth.make_detections(B, c["R0"], c["D"], seed=seed))
+    ctrl = torch.from_numpy(synth.make_ctrl(B, c["L"], c["R"], c["D"], seed=seed))
+    name = "beam-%d" % beam if beam > 1 else "greedy"
     out = {}
-    for flavour in ("as_written", "hoisted"):
+    for flavour, n_timed in (("as_written", 2 if full_B > 0 else 3), ("hoisted", 3)):
         o = vo.Oracle(weights, c["T"], 2, as_written=flavour == "as_written")
         run = (lambda d, r: o.beam_search(d, r, [EOS, -1], beam, 1)) if beam > 1 else (lambda d, r: o.test(d, r))
         ts = []
         with torch.no_grad():
-            run(det[:2], ctrl[:2])
-            for _ in range(3):
+            t0 = time.time()
+            run(det, ctrl) if full_B > 0 else run(det[:2], ctrl[:2])          # warm-up (allocator, thread pool at these shapes)
+            warm = time.time() - t0
+            for _ in range(n_timed):
                 t0 = time.time()
                 run(det, ctrl)
                 ts.append(time.time() - t0)
-        out[flavour] = (sample_B * c["T"] / sorted(ts)[1], sorted(ts)[1])
-    name = "beam-%d" % beam if beam > 1 else "greedy"
-    res = dict(value=out["as_written"][0], unit="tokens/s", cores=torch.get_num_threads(), kind="port",
-               cpu_model=model, torch=torch.__version__, hoisted_value=out["hoisted"][0], sample_B=sample_B,
-               sample="oracle/vsr_oracle.py, %s, %d images x %d steps, fp32; as-written (the reference's op order) median of 3 = "
-                      "%.1f s per call, hoisted variant %.1f s; 1 warm-up call each" %
-                      (name, sample_B, c["T"], out["as_written"][1], out["hoisted"][1]))
-    if full_B > sample_B:
-        det = torch.from_numpy(synth.make_detections(full_B, c["R0"], c["D"], seed=1000))        # the GPU leg's first batch
-        ctrl = torch.from_numpy(synth.make_ctrl(full_B, c["L"], c["R"], c["D"], seed=1000))
-        o = vo.Oracle(weights, c["T"], 2, as_written=True)
-        times = []
-        with torch.no_grad():
-            for _ in range(2):                   # a warm-up call at the full size (allocator, thread pool at these shapes), then the timed one
-                t0 = time.time()
-                (o.beam_search(det, ctrl, [EOS, -1], beam, 1) if beam > 1 else o.test(det, ctrl))
-                times.append(time.time() - t0)
-        dt = times[1]
-        res.update(value=full_B * c["T"] / dt, sample_B=full_B, sample12_value=out["as_written"][0], first_call_value=full_B * c["T"] / times[0],
-                   sample="oracle/vsr_oracle.py, %s, as-written (the reference's op order), fp32: the SECOND of two calls on the GPU leg's own "
-                          "first batch of %d images x %d steps = %.1f s (value; the first, un-warmed call took %.1f s: first_call_value - the "
-                          "round-3 line reported that one); bounded sample of %d images, median of 3 after a warm-up: "
-                          "%.1f s per call as written (sample12_value), %.1f s hoisted (hoisted_value)" %
-                          (name, full_B, c["T"], dt, times[0], sample_B, out["as_written"][1], out["hoisted"][1]))
-    return res
+        ts.sort()
+        med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+        out[flavour] = dict(med=med, best=ts[0], warm=warm, n=n_timed)
+    tok = B * c["T"]
+    aw, ho = out["as_written"], out["hoisted"]
+    return dict(value=tok / aw["med"], unit="tokens/s", cores=torch.get_num_threads(), kind="port", cpu_model=model, torch=torch.__version__,
+                value_best=tok / aw["best"], hoisted_value=tok / ho["med"], hoisted_value_best=tok / ho["best"], sample_B=B,
+                timed_calls={"as_written": aw["n"], "hoisted": ho["n"]},
+                sample="oracle/vsr_oracle.py, %s, fp32, %s%d images x %d steps; as written (the reference's op order): 1 warm-up call (%.1f s) + %d timed, "
+                       "median %.1f s / best %.1f s per call = value / value_best; hoisted variant on the same inputs: warm-up %.1f s + %d timed, median %.1f s / best "
+                       "%.1f s = hoisted_value / hoisted_value_best" %
+                       (name, "the GPU leg's own first batch, " if full_B > 0 else "bounded sample, ", B, c["T"], aw["warm"], aw["n"], aw["med"], aw["best"],
+                        ho["warm"], ho["n"], ho["med"], ho["best"]))
 
 
 def cpu_baseline_xe(weights, sample_B, torch, synth):
@@ -233,13 +227,13 @@ class Dist:
         return int(t.item())
 
 
-def make_model(torch, synth, dev, train, dtype):
+def make_model(torch, synth, dev, train, dtype, verb_table=None):
     from models import ControllableCaptioningModel
     c = CFG
     gains = {k: 1.0 for k in synth.DEFAULT_GAINS} if train else None
     weights = synth.make_weights(c["V"], c["D"], c["E"], c["H"], c["A"], seed=0, gains=gains)
     m = ControllableCaptioningModel(c["T"], c["V"], 2, det_feat_size=c["D"], input_encoding_size=c["E"], rnn_size=c["H"],
-                                    att_size=c["A"], verb_2_vob_all={})
+                                    att_size=c["A"], verb_2_vob_all=verb_table or {})
     m.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     m = m.to(dev)
     m = m.train() if train else m.eval()
@@ -359,8 +353,8 @@ def decode_bench(args, D, torch, dist, synth):
         "value": images * c["T"] * args.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "%s decode, batch %s, 36 regions x 2048-d, 10 slots, seq_len 20, vocab 10000 (BASELINE configs[%d])" %
-                               (name, "100 images split over the ranks (13/12 per GPU at 8)" if strong else "100 images/GPU", 2 if beam > 1 else 1),
+        "config": {"workload": "%s decode, batch %s, %d regions x 2048-d, 10 slots, seq_len 20, vocab 10000 (BASELINE configs[%d])" %
+                               (name, "%d images split over the ranks (13/12 per GPU at 8)" % c["B"] if strong else "%d images/GPU" % c["B"], c["R"], 2 if beam > 1 else 1),
                    "beam": beam, "batch_per_gpu": hi - lo, "seq_len": c["T"],
                    "parallelism": "images sharded, dp%d%s" % (world, ", ids all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo self-test") if strong else ", no data-path collective"),
                    "rccl_world_size_observed": D.observed_world(), "collective_backend": args.backend,
@@ -385,6 +379,54 @@ def decode_bench(args, D, torch, dist, synth):
     del m, batches
     torch.cuda.empty_cache()
     return line, weights, beam
+
+
+# ---------------------------------------------------------------------------------------------- eval-side caller (C3 / N1)
+def eval_bench(args, D, torch, dist, synth):
+    """coco_scripts/eval_coco.py:240-247 at the shapes the real caller feeds: per image the pooled detections (100 x 2048), n_caps = 5
+    caption rows of 10 slots x 20 regions and a verb list; 16 images of a loader batch decoded by ONE beam_search_v call through
+    vsrcap.evalbatch.beam_search_v_batched (M = 80 / 400 rows).  tokens/s = caption rows x T / wall time."""
+    from vsrcap import evalbatch
+    c = dict(CFG, R0=100, R=20, L=10)
+    n_img, n_caps, nv = 16, 5, 8
+    dev = D.dev
+    m, weights = make_model(torch, synth, dev, False, args.dtype, verb_table=synth.make_verb_table(nv, c["V"], seed=0))
+    batches = []
+    for i in range(2):
+        seed = 3000 + i + 10 * D.rank
+        det = torch.from_numpy(synth.make_detections(n_img, c["R0"], c["D"], seed=seed)).to(dev)
+        seqs = torch.from_numpy(synth.make_ctrl(n_img * n_caps, c["L"], c["R"], c["D"], seed=seed)).to(dev)
+        verbs = torch.from_numpy(synth.make_verbs(n_img * n_caps, c["L"], nv, seed=seed, p=0.15)).to(dev)
+        batches.append([(det[j], seqs[j * n_caps:(j + 1) * n_caps], verbs[j * n_caps:(j + 1) * n_caps]) for j in range(n_img)])
+
+    def one_step(i):
+        with torch.no_grad():
+            return evalbatch.beam_search_v_batched(m, batches[i & 1], [EOS, -1], BEAM, 1, gt=False)
+
+    for i in range(args.warmup):
+        one_step(i)
+    eng = m._engine(dev)
+    D.barrier()
+    eng.profile_begin(every=PROFILE_EVERY)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    D.barrier()
+    dt = time.perf_counter() - t0
+    gemm_seen, gemm_bytes = eng.profile_seen(), eng.profile_bytes()
+    gemm_ms, gemm_n, gemm_flops = eng.profile_end(dev)
+    dt = D.max_time(dt)
+    rows = n_img * n_caps * D.world
+    line = {"metric": "decoded tokens/sec, beam_search_v at the eval caller's shapes (16 images x 5 caption rows, beam 5)",
+            "value": rows * c["T"] * args.steps / dt, "unit": "tokens/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "beam_search_v (verb forcing, gt=False) through evalbatch.beam_search_v_batched: 16 images x 5 caption rows per GPU, 100 pooled "
+                                   "detections x 2048-d, 10 slots x 20 regions, seq_len 20, vocab 10000, beam 5 (eval_coco.py:55-57,240-247; data/field.py:18,115)",
+                       "beam": BEAM, "rows_per_gpu": n_img * n_caps, "seq_len": c["T"], "parallelism": "dp%d, no data-path collective" % D.world},
+            "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, None, None, gemm_bytes)}
+    del m, batches
+    torch.cuda.empty_cache()
+    return line, weights
 
 
 # ---------------------------------------------------------------------------------------------- training
@@ -463,8 +505,9 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
         "value": images * steps / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("XE training step (forward + NLL losses + BPTT backward + torch.optim.Adam(fused=True)), batch %s, 20 slots x 36 regions x 2048-d, "
-                                "seq_len 20, vocab 10000 (BASELINE configs[3] shapes)" % ("100 split over the ranks" if strong else "100/GPU")) if xe else
+        "config": {"workload": ("XE training step (forward + NLL losses + BPTT backward + torch.optim.Adam(fused=True)), batch %s, %d pooled detections, 20 slots x %d regions x 2048-d, "
+                                "seq_len 20, vocab 10000 (%s)" % ("100 split over the ranks" if strong else "100/GPU", c["R0"], c["R"],
+                                                                   "BASELINE configs[3] shapes" if (c["R0"], c["R"]) == (36, 36) else "the real callers' shapes: data/field.py:18,115, coco_scripts/train.py:39-41")) if xe else
                                ("SCST step: greedy baseline (100 images) + sample_rl on 500 rows (5 samples/image) + replayed forward + BPTT "
                                 "backward + Adam(fused=True), rewards = device CIDEr-D vs synthetic references, 10 slots x 36 x 2048 (BASELINE configs[4])"),
                    "batch_per_gpu": hi - lo, "seq_len": c["T"],
@@ -483,7 +526,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="beam5", choices=["beam5", "beam5idx", "greedy", "xe", "xeidx", "scst"])
+    ap.add_argument("--workload", default="beam5", choices=["beam5", "beam5idx", "greedy", "xe", "xeidx", "scst", "xe_real", "beam5_eval"],
+                    help="xe_real / beam5_eval: the XE step and the eval-side beam_search_v call at the shapes the reference's real callers feed "
+                         "(100 pooled detections, slots of 20 regions; 16 images x 5 caption rows)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--dtype", default="f16x2", choices=["f32", "f32x3", "f16x2", "bf16"],
                     help="f16x2 = parity mode (headline): fp32 operands in memory, fp32 accumulation, every product from two fp16 terms per operand "
@@ -514,7 +559,14 @@ def main():
     if args.gpus != D.world and D.rank == 0:
         print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, D.world, D.world), file=sys.stderr)
 
-    if args.workload in ("xe", "xeidx", "scst"):
+    if args.workload == "beam5_eval":
+        line, weights = eval_bench(args, D, torch, dist, synth)
+    elif args.workload == "xe_real":
+        CFG.update(R0=100, R=20)
+        args.workload = "xe"
+        line, weights = train_bench(args, D, torch, dist, synth, args.steps, args.warmup)
+        line["metric"] = "XE-step samples/sec at the real callers' shapes (100 pooled detections, 20 slots x 20 regions)"
+    elif args.workload in ("xe", "xeidx", "scst"):
         line, weights = train_bench(args, D, torch, dist, synth, args.steps, args.warmup)
         if D.rank == 0 and D.world == 1 and not args.no_cpu and args.workload == "xe":
             line["cpu_baseline"] = cpu_baseline_xe(weights, min(args.cpu_sample, 16), torch, synth)
@@ -571,11 +623,55 @@ def main():
                 finally:
                     CFG["B"] = old_b
                 return {k: al[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype")} | {"batch": batch, "gemm_avg_launch_us": al["roofline"]["avg_launch_us"]}
+            def real_xe_leg():
+                xb = argparse.Namespace(**vars(args))
+                xb.workload = "xe"
+                old = (CFG["R0"], CFG["R"])
+                CFG.update(R0=100, R=20)
+                try:
+                    bl, _ = train_bench(xb, D, torch, dist, synth, max(5, args.steps // 2), 2)
+                finally:
+                    CFG.update(R0=old[0], R=old[1])
+                return {k: bl[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype")} | {"workload": bl["config"]["workload"], "roofline_frac": bl["roofline"]["frac"]}
+
+            def eval_leg():
+                aa = argparse.Namespace(**vars(args))
+                aa.steps, aa.warmup = max(10, args.steps), 3
+                bl, _ = eval_bench(aa, D, torch, dist, synth)
+                return {k: bl[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "dtype")} | {"workload": bl["config"]["workload"]}
             if args.batch == 0 and D.world == 1:
                 line["alt_workloads"] = {"greedy": optional("greedy leg", lambda: workload_leg("greedy", CFG["B"])),
-                                         "beam5_batch13": optional("13-image leg", lambda: workload_leg("beam5", 13))}
+                                         "beam5_batch13": optional("13-image leg", lambda: workload_leg("beam5", 13)),
+                                         "xe_real": optional("real-shape XE leg", real_xe_leg),
+                                         "beam5_eval": optional("eval-caller leg", eval_leg)}
         if D.rank == 0 and D.world == 1 and not args.no_cpu and args.workload != "beam5idx":
             line["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample, beam, torch, synth, full_B=CFG["B"] if args.cpu_full else 0)
+        # The driver's record keeps the standard top-level keys and `config`: the other half of BASELINE.json's metric (XE samples/s), the
+        # exact-chain flavour and the one-m-tile regimes are therefore ALSO summarised inside `config` (full legs: `secondary`, `alt_modes`,
+        # `alt_workloads` of this same line).  `vs_baseline` stays null (BASELINE.md holds no published number for this metric); the ratio to
+        # the CPU baseline timed in this run - BASELINE.md section 4's ">= 50x" target - is config.vs_cpu_baseline.
+        def pick(d, *keys):
+            for k in keys:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        cfgk = line["config"]
+        sec = line.get("secondary")
+        if pick(sec, "value") is not None:
+            cfgk["xe_samples_per_s"], cfgk["xe_ms_per_step"] = sec["value"], sec["ms_per_step"]
+            cfgk["xe_roofline_frac"] = pick(sec, "roofline", "frac")
+            for dt in ("f32", "bf16"):
+                if pick(sec, "alt_modes", dt, "value") is not None:
+                    cfgk["xe_%s_samples_per_s" % dt] = sec["alt_modes"][dt]["value"]
+        for dt, key in (("f32", "f32_exact_tokens_per_s"), ("f32x3", "f32x3_tokens_per_s"), ("bf16", "bf16_tokens_per_s")):
+            if pick(line, "alt_modes", dt, "value") is not None:
+                cfgk[key] = line["alt_modes"][dt]["value"]
+        for wl, key, field in (("greedy", "greedy_tokens_per_s", "value"), ("beam5_batch13", "batch13_ms", "ms_per_step"),
+                               ("xe_real", "xe_real_samples_per_s", "value"), ("beam5_eval", "beam5_eval_tokens_per_s", "value")):
+            if pick(line, "alt_workloads", wl, field) is not None:
+                cfgk[key] = line["alt_workloads"][wl][field]
+        if pick(line, "cpu_baseline", "value"):
+            cfgk["vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+            cfgk["vs_cpu_baseline_hoisted"] = line["value"] / line["cpu_baseline"]["hoisted_value"]
     if D.rank == 0:
         print(json.dumps(line), flush=True)
     if D.world > 1:

@@ -21,6 +21,12 @@ Fixtures:
                                           log-probs; SCST gradient norms of a 40-row slice replaying those draws
   g10_fresh                               2 FRESH seeds x 48 images (no margin search): reference greedy + beam-5 tokens,
                                           fp64-oracle margins / agreement flags
+  g12_real_shapes                         the shapes the real callers feed (data/field.py:18,115, coco_scripts/train.py:39-41,
+                                          eval_coco.py:55-57,240-247): XE step at B = 100 with R0 = 100 pooled detections, slots of
+                                          R = 20 regions, L = T = 20; beam_search_v over 16 images x 5 caption rows (L = 10, R = 20,
+                                          verbs, beam 5), called per image like the eval script does
+  g13_flip1024                            16 FRESH seeds x 64 images (no margin search): greedy + beam-5 ids of the reference (fp32)
+                                          AND of the fp64 oracle, greedy margins, beam score gaps - the flip-rate fixture
 """
 import json
 import os
@@ -122,7 +128,8 @@ def pick_seed_and_greedy(c):
 
 def main():
     """Stages are independent and resumable:
-    python tests/golden/make_golden.py [small] [greedy] [beam] [verbs] [sample] [stepv] [xe100] [scst500] [fresh]"""
+    python tests/golden/make_golden.py [small] [greedy] [beam] [verbs] [sample] [stepv] [xe100] [scst500] [fresh] [real] [flip1024]
+    (the last two only on request: they take ~1 h of CPU)"""
     stages = sys.argv[1:] or ["small", "greedy", "beam", "verbs", "sample", "stepv", "xe100", "scst500", "fresh"]
     torch.manual_seed(0)
     tmp = tempfile.mkdtemp()
@@ -149,6 +156,12 @@ def main():
         stage_scst500()
     if "fresh" in stages:
         stage_fresh()
+    if "real" in stages:
+        stage_real()
+    if "flip1024" in stages:
+        stage_flip1024()
+    if not (set(stages) - {"small", "stepv", "xe100", "scst500", "fresh", "real", "flip1024"}):
+        return
     cF = cfg_full(256)
     if "greedy" in stages:
         stage_greedy(cF)
@@ -312,6 +325,99 @@ def stage_fresh():
                        "margins_%d" % seed: marg.numpy().astype(np.float32), "greedy_agree64_%d" % seed: g_ok.numpy(),
                        "beam_agree64_%d" % seed: b_ok.numpy()})
     save("g10_fresh", dict(cfg=c, seeds=seeds, wseed=0, bos=BOS, eos=[3, -1]), **arrays)
+
+
+def stage_real():
+    """The shapes of the REAL callers (the synthetic BASELINE configs pool 36 detections and use slots of 36 regions):
+    detections (B, 100, 2048) (data/field.py:115), slots of 20 regions (field.py:18), fixed_len 20 in training
+    (coco_scripts/train.py:39-41) and 10 in evaluation (eval_coco.py:55-57), ~5 caption rows per image, each image its own
+    beam_search_v call with the image's detections expanded over its rows (eval_coco.py:240-247)."""
+    # ---- XE step, B = 100, R0 = 100, R = 20, L = T = 20
+    c = dict(V=10000, B=100, R0=100, R=20, D=2048, L=20, T=20, E=1000, H=1000, A=512)
+    gains = {k: 1.0 for k in synth.DEFAULT_GAINS}
+    seed = 31
+    t0 = time.time()
+    m, w = build_ref(c, gains)
+    m.train()
+    det, ctrl_seq = inputs(c, seed, train=True)
+    caps = torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed))
+    gts = torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed))
+    out, gate = m((det,), (caps, ctrl_seq))
+    loss, lc, lg = vo.xe_loss(out, gate, caps, gts)
+    loss.backward()
+    gnorm = np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()], dtype=np.float64)
+    gsum = np.array([float(p.grad.double().sum()) for _, p in m.named_parameters()], dtype=np.float64)
+    tgt = out.detach()[:, :-1].gather(2, caps[:, 1:, None])[:, :, 0]
+    xe = dict(xe_gate=gate.detach().numpy(), xe_out_at_target=tgt.numpy(), xe_out_max=out.detach().max(-1)[0].numpy(),
+              xe_out_argmax=out.detach().argmax(-1).numpy().astype(np.int32),
+              xe_losses=np.array([loss.item(), lc.item(), lg.item()], dtype=np.float64), xe_grad_norm=gnorm, xe_grad_sum=gsum)
+    print("real-shape XE step %.1fs: loss %.6f" % (time.time() - t0, loss.item()), flush=True)
+    del m, out, gate, loss
+    # ---- eval: 16 images x 5 caption rows, per-image beam_search_v calls (the default decode gains: diverse tokens)
+    ce = dict(V=10000, B=80, R0=100, R=20, D=2048, L=10, T=20, E=1000, H=1000, A=512)
+    n_img, n_caps, eseed = 16, 5, 41
+    m, w = build_ref(ce)
+    m.eval()
+    det = torch.from_numpy(synth.make_detections(n_img, ce["R0"], ce["D"], seed=eseed))
+    seqs = torch.from_numpy(synth.make_ctrl(n_img * n_caps, ce["L"], ce["R"], ce["D"], seed=eseed))
+    verbs = torch.from_numpy(synth.make_verbs(n_img * n_caps, ce["L"], NV, seed=eseed, p=0.15))
+    o64 = vo.Oracle(w, ce["T"], BOS, as_written=False, dtype=torch.float64)
+    ev = {}
+    t0 = time.time()
+    with torch.no_grad():
+        for gt in (False, True):
+            ws, gs = [], []
+            for i in range(n_img):
+                lo, hi = i * n_caps, (i + 1) * n_caps
+                st = (det[i:i + 1].expand(n_caps, ce["R0"], ce["D"]), seqs[lo:hi], verbs[lo:hi])
+                (vw, vg), _ = m.beam_search_v(st, [3, -1], 5, 1, gt=gt)
+                ws.append(vw)
+                gs.append(vg)
+            ev["eval_words_gt%d" % gt] = torch.cat(ws).numpy().astype(np.int16)
+            ev["eval_gates_gt%d" % gt] = torch.cat(gs).numpy().astype(np.int8)
+        # the same rows without verbs, against the fp64 oracle: which rows are numerically solid
+        dexp = det.repeat_interleave(n_caps, 0)
+        (bw, bg), _ = m.beam_search((dexp, seqs), [3, -1], 5, 1)
+        (ow, og), _, sc = o64.beam_search(dexp.double(), seqs.double(), [3, -1], 5, 1, return_scores=True)
+    ev["eval_words_noverb"] = bw.numpy().astype(np.int16)
+    ev["eval_gates_noverb"] = bg.numpy().astype(np.int8)
+    ev["eval_noverb_agree64"] = ((ow == bw).all(1) & (og == bg).all(1)).numpy()
+    print("real-shape eval %.1fs: no-verb rows ref==fp64 %d/%d" % (time.time() - t0, int(ev["eval_noverb_agree64"].sum()), n_img * n_caps), flush=True)
+    save("g12_real_shapes", dict(cfg_xe=c, gains_xe=gains, seed_xe=seed, cfg_eval=ce, seed_eval=eseed, n_img=n_img, n_caps=n_caps, nv=NV, verb_p=0.15,
+                                 wseed=0, bos=BOS, eos=[3, -1], param_order=list(w.keys())), **xe, **ev)
+
+
+def stage_flip1024():
+    """16 fresh input seeds x 64 images at full size, no margin search: greedy and beam-5 ids of the REFERENCE (fp32, as it runs on
+    this CPU) and of the fp64 oracle.  The test counts, per GEMM flavour, the captions that differ from the fp64 ids, next to
+    the reference's own count (an fp32 implementation cannot be asked for fewer flips than the reference itself shows)."""
+    c = cfg_full(64)
+    m, w = build_ref(c)
+    m.eval()
+    o64 = vo.Oracle(w, c["T"], BOS, as_written=False, dtype=torch.float64)
+    seeds = list(range(2001, 2017))
+    acc = {k: [] for k in ("gw", "gg", "bw", "bg", "gw64", "gg64", "bw64", "bg64", "marg", "gap64")}
+    for seed in seeds:
+        det, ctrl = inputs(c, seed)
+        t0 = time.time()
+        with torch.no_grad():
+            gw, gg = m.test(det, ctrl)
+            (bw, bg), _ = m.beam_search((det, ctrl), [3, -1], 5, 1)
+            w64, g64, marg, ks, _ = o64.test(det.double(), ctrl.double(), return_trace=True)
+            (ow, og), _, sc = o64.beam_search(det.double(), ctrl.double(), [3, -1], 5, 2, return_scores=True)
+        g_ok = (w64 == gw).all(1) & (g64 == gg).all(1)
+        b_ok = (ow[:, 0] == bw).all(1) & (og[:, 0] == bg).all(1)
+        print("seed %d: greedy ref==fp64 %d/64, beam ref==fp64 %d/64, %.0fs" % (seed, int(g_ok.sum()), int(b_ok.sum()), time.time() - t0), flush=True)
+        for k, v in (("gw", gw), ("gg", gg), ("bw", bw), ("bg", bg), ("gw64", w64), ("gg64", g64), ("bw64", ow[:, 0]), ("bg64", og[:, 0]),
+                     ("marg", marg.min(1)[0]), ("gap64", sc[:, 0] - sc[:, 1])):
+            acc[k].append(v.numpy())
+    cat = {k: np.concatenate(v) for k, v in acc.items()}
+    save("g13_flip1024", dict(cfg=c, seeds=seeds, wseed=0, bos=BOS, eos=[3, -1]),
+         greedy_words=cat["gw"].astype(np.int16), greedy_gates=cat["gg"].astype(np.int8),
+         beam_words=cat["bw"].astype(np.int16), beam_gates=cat["bg"].astype(np.int8),
+         greedy_words64=cat["gw64"].astype(np.int16), greedy_gates64=cat["gg64"].astype(np.int8),
+         beam_words64=cat["bw64"].astype(np.int16), beam_gates64=cat["bg64"].astype(np.int8),
+         greedy_min_margin=cat["marg"].astype(np.float32), beam_gap64=cat["gap64"].astype(np.float32))
 
 
 def stage_greedy(cF):

@@ -7,7 +7,7 @@
 // summation order.  v_mfma_f32_32x32x16_bf16 does 16 k per 32 cycles: six of them replace eight fp32 MFMAs of 64
 // cycles (192 vs 512 cycles per 16 k).
 #pragma once
-#include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
+#include "../../vsr-guided-cic_amd/csrc/gemm_f32.h"
 
 namespace vsr {
 

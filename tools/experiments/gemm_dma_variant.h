@@ -1,7 +1,7 @@
 // Experiment kept for tools/gemm_bench.hip only (NOT part of libvsrcap.so): the stream-K fp32 GEMM with LDS-DMA tile loads.
 // Measured bit-identical to and as fast as the register-staged kernel (91.1 vs 91.7 TF/s on the step shapes).
 #pragma once
-#include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
+#include "../../vsr-guided-cic_amd/csrc/gemm_f32.h"
 
 namespace vsr {
 

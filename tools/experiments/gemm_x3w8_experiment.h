@@ -9,7 +9,7 @@
 // copies an asm-loaded register before its `landed` marker once the live ranges grow): not pursued.
 // To build it again: include this file behind csrc/gemm_x3.h inside namespace-less context and add a launch case to tools/gemm_bench.hip.
 #pragma once
-#include "../vsr-guided-cic_amd/csrc/gemm_x3.h"
+#include "../../vsr-guided-cic_amd/csrc/gemm_x3.h"
 
 namespace vsr {
 // ------------------------------------------------------------------------------------------------------------------

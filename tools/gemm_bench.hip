@@ -14,8 +14,8 @@
 // `git show 4789752:tools/ablate/gemm_f32.h` etc.  tools/x3_ablate.py patches scratch copies of the shipped headers instead.
 #define GEMM_ABLATE 0
 #include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
-#include "gemm_bf16x3.h"
-#include "gemm_dma_variant.h"
+#include "experiments/gemm_bf16x3.h"
+#include "experiments/gemm_dma_variant.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_bf16.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_x3.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_x3s.h"

@@ -235,6 +235,7 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     h->b16.resize(h->b16_weights);                         // (re)register the bf16 twins of this workspace
     for (const TrainCtx::Twin& tw : t.twins) h->b16.push_back(Bf16Range{tw.f, tw.f + tw.n, tw.b});
     h->h2t.clear();                                        // ... and the fp16-pair images
+    h->h2t_only = false;
     for (const TrainCtx::Img& im : t.imgs) h->h2t.push_back(H2Range{im.f, im.f + im.n, t.h2img + im.off, im.slot});
     const int TB = T * B;
     const size_t BH = (size_t)B * H;
@@ -443,7 +444,10 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     // f16x2 flavour: the W operands of the backward GEMMs - transposed weights here, transposed activations in phase B - are written as
     // fp16-pair images by the transposing kernel itself; the A operands are gradients: their producers fold max |x| into "dynamic" slots
     // of the exponent table (block tt of 8 slots for step tt, blocks 62 / 63 for the whole-pass operands)
-    const bool h2b = h->h2_on && !h->bf16_on && t.h2img && T <= 62;
+    // (the same conditions GemmBuilder::finish() routes a launch to the f16x2 kernels by: a backward pass that wrote only images for
+    // launches that then fall through to the fp32-operand kernels would read unwritten buffers - finish() refuses such a launch too)
+    const bool h2b = h->h2_on && h->x3_on && h->gemm_tile == 0 && !h->bf16_on && t.h2img && T <= H2_NDYN / 8 - 2;
+    h->h2t_only = h2b;
     int* dyn = h2b ? h->h2_exps + H2_DYN0 : nullptr;
     enum { DY_dpre2, DY_dga, DY_dq, DY_dhA, DY_dsent, DY_dsa, DY_dpre1 };               // per-step block
     enum { DW_dlogits = 62 * 8, DW_dP, DW_dpre1sum, DW_dpre2sum, DW_dpre1all, DW_step = 63 * 8 };      // whole-pass slots (DW_step + DY_x: max over the steps)

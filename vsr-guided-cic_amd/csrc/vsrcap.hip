@@ -82,6 +82,9 @@ struct Ctx {
     uint16_t* st16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     uint16_t *s_t16 = nullptr, *g_t16 = nullptr, *att16 = nullptr;
     bool st16_ok[2] = {false, false};
+    int* tickets = nullptr;      // in-launch combine (gemm_epi.h): arrival counters of a launch's tiles; all zero between launches
+    int tickets_cap = 0;
+    float* ga = nullptr;         // att_ga(g_t) sums when the LSTM2 launch combines them itself (M, A)
     float* pre1 = nullptr;       // LSTM1/gate sums of the NEXT step, produced early (merged with the vocabulary GEMM)
     int pre1_ns = 0, pre1_nblk = 0;
     long long pre1_stride = 0;
@@ -118,15 +121,30 @@ struct vsr_handle {
     // and launches whose A operands all have one take the all-DMA kernel (gemm_h2a.h); VSR_H2_AIMG=0: in-kernel split of fp32 A only
     double aligned_eff_min = 0.75;    // wide launches: k-aligned pieces when they keep at least this share of the CUs busy, stream-K ranges otherwise (VSR_ALIGNED_EFF, percent)
     bool h2_aimg = true;
+    // in-launch combine of the k-pieces with the pointwise consumer as the last arriver's epilogue (gemm_epi.h), all-DMA kernel only.
+    // VSR_FUSE bits: 1 = S2 (g_t, hA, s_a, sentinel: k_attend's slab phase), 2 = S5 (LSTM2 cell: k_lstm2; att_ga sums), 4 = S6 (the
+    // vocabulary logits and the next step's LSTM1 sums reach k_vocab / k_lstm1 as ONE slab)
+    int fuse = 7;
     bool b16_dma = true;              // bf16 mode: launches whose A operands all have bf16 images take the all-DMA kernel (VSR_B16_DMA=0: register-staged)
     int h2a_max_small = 128;          // launches of at most this many rows (and more than h2s_max) : 128 x 128 tiles of the all-DMA kernel
     std::vector<H2Range> h2t;         // the training pass's transposed operands (vsr_train_forward registers the images of its workspace)
-    const H2Range* map_h2(const float* p) const {
+    const H2Range* map_h2(const float* p, bool with_train = true) const {
         for (const H2Range& r : h2)
             if (p >= r.lo && p < r.hi) return &r;
-        for (const H2Range& r : h2t)
-            if (p >= r.lo && p < r.hi) return &r;
+        if (with_train)
+            for (const H2Range& r : h2t)
+                if (p >= r.lo && p < r.hi) return &r;
         return nullptr;
+    }
+    // A operands are looked up among the images registered at refresh only (the embedding table): the training workspace's
+    // ranges (h2t) describe W operands and may outlive the memory they were registered for
+    const H2Range* map_h2_a(const float* p) const { return map_h2(p, false); }
+    bool h2t_only = false;            // the running backward pass writes ONLY the images of its transposed operands (train.inc.h: h2b)
+    bool is_h2_train_image(const float* p) const {      // p lies in a transposed operand of the training pass that exists ONLY as an fp16-pair image
+        if (!h2t_only) return false;
+        for (const H2Range& r : h2t)
+            if (p >= r.lo && p < r.hi) return true;
+        return false;
     }
     int h2_slot_of(const float* p) const { const H2Range* r = map_h2(p); return r ? r->slot : 0; }
     bool x3_on = true;                // launches of >= gemm_x3_min_rows rows: fp32 products through three bf16 terms per operand (gemm_f32x3.h); fp32 operands, no copies.  vsr_set_gemm_mode(h, 0): exact fma chain everywhere
@@ -263,6 +281,9 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     c.scratch_floats = std::max(stage * 8, std::max(rows, prows) * A * 8);   // att_va slabs of prepare(): over the bank rows when indexed
     c.scratch = b.take<float>(c.scratch_floats);
     c.pre1 = b.take<float>(M * 6 * H * 8);
+    c.ga = b.take<float>(M * A);
+    c.tickets_cap = (int)(((M + 127) / 128) * ((6 * H + (H + A) + (D + A) + 4 * H + A + V) / 128 + 16));     // >= the tiles of any one launch (128-wide tiles)
+    c.tickets = b.take<int>((size_t)c.tickets_cap);
     b.off = (b.off + 15) & ~size_t(15);
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j) c.st16[i][j] = b.take<uint16_t>(2 * ((M * H + 7) & ~size_t(7)));      // (bf16: 2 bytes per element; fp16 pairs: 4)
@@ -296,6 +317,7 @@ struct GemmBuilder {
     bool keep_fp32 = false; // bf16 mode: this launch stays fp32-equivalent (f32x3 kernels): the hoisted att_va(regions) projection, whose
                             // outputs are summed RAW over up to 36 rows into the shift logit (step :187) - bf16 rounding adds up coherently there
     bool a_image_only = false;   // f16x2 flavour: an A operand exists ONLY as an fp16-pair image (GemmSeg::A16; the training pass's transposed gradients): the launch must take the all-DMA kernel
+    bool stale_h2 = false;  // f16x2 flavour: a W operand exists only as an fp16-pair image (a transposed operand of the training pass) but the launch does not take an f16x2 kernel
     bool stale_w = false;   // bf16 mode: a W operand exists only as a bf16 image but the launch does not qualify for the bf16 kernel
     // stream-K plan: returns the slab count; the caller then sets every problem's C / slab_stride
     int finish(const vsr_handle* h) {
@@ -364,7 +386,7 @@ struct GemmBuilder {
                 for (int i = 0; i < ah.nprob && aimg; ++i)
                     for (int sg = 0; sg < ah.p[i].nseg && aimg; ++sg) {
                         const GemmSeg& S = ah.p[i].seg[sg];
-                        const H2Range* ra = S.A16 ? nullptr : h->map_h2(S.A);
+                        const H2Range* ra = S.A16 ? nullptr : h->map_h2_a(S.A);
                         aimg = (S.lda % 8 == 0) && (S.A16 ? (reinterpret_cast<uintptr_t>(S.A16) & 31) == 0
                                                           : (ra && ra->slot == (S.exp_idx >> 16) && (S.A - ra->lo) % 8 == 0));
                     }
@@ -373,7 +395,7 @@ struct GemmBuilder {
                         for (int sg = 0; sg < g.p[i].nseg; ++sg) {
                             GemmSeg& S = g.p[i].seg[sg];
                             if (S.A16) S.A = reinterpret_cast<const float*>(S.A16);
-                            else { const H2Range* ra = h->map_h2(S.A); S.A = ra->img + (S.A - ra->lo); }
+                            else { const H2Range* ra = h->map_h2_a(S.A); S.A = ra->img + (S.A - ra->lo); }
                         }
                 };
                 const int slots = h->gemm_slots_bf16;
@@ -410,6 +432,10 @@ struct GemmBuilder {
                 return gemm_plan(a, slots, 4, 128, 256, H2_BK);
             }
         }
+        // from here on the launch reads fp32 operands: the transposing kernels of an f16x2 backward pass wrote ONLY the images of theirs
+        if (h->h2_on && !h->bf16_on)
+            for (int i = 0; i < a.nprob; ++i)
+                for (int sg = 0; sg < a.p[i].nseg; ++sg) stale_h2 = stale_h2 || h->is_h2_train_image(a.p[i].seg[sg].W);
         if ((h->x3_on || (keep_fp32 && h->bf16_on && h->bf16_p_fp32)) && h->gemm_tile == 0) {
             // f32x3 (gemm_x3.h): 128 x 256 tiles from 193 rows up; 128 x 128 tiles for launches whose rows fit ONE m-tile (greedy
             // decoding, sampling, the per-step GEMMs of the training pass at batch 100, a shard of a strong-scaled decode): the
@@ -480,10 +506,29 @@ struct GemmBuilder {
         // tiles are cut into ~3 stream-K pieces instead of ~5, so every consumer kernel reads 40 % fewer slab bytes.
         return gemm_plan(a, big ? h->gemm_slots / 2 : h->gemm_slots_small, h->gemm_min_iters, big ? 128 : 64, big == 2 ? 128 : 64);
     }
+    // In-launch combine: the launch takes the all-DMA kernel and problem i is 16-byte clean (N, ldc, slab stride multiples of 4, aligned
+    // base).  Call after finish() and after the caller has set C / slab_stride.
+    bool can_combine(int i) const {
+        const GemmProb& p = a.p[i];
+        return big == 37 && (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.slab_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    }
+    // hand the problems with an epilogue their ticket ranges; false (and every epilogue off) when the counters do not suffice
+    bool assign_tickets(int* tickets, int cap) {
+        int t = 0;
+        for (int i = 0; i < a.nprob; ++i)
+            if (a.p[i].epi.kind != EPI_NONE) { a.p[i].epi.tick0 = t; t += a.p[i].tiles_m * a.p[i].tiles_n; }
+        if (t > cap) {
+            for (int i = 0; i < a.nprob; ++i) { a.p[i].epi.kind = EPI_NONE; a.p[i].wperm_shift = 0; }
+            return false;
+        }
+        a.tickets = tickets;
+        return true;
+    }
     int launch(hipStream_t s, vsr_handle* h);
 };
 
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
+    if (stale_h2) return fail("f16x2 flavour: a GEMM launch names a transposed operand of the training pass that only exists as an fp16-pair image but cannot take an f16x2 kernel (gemm mode / tile override changed since vsr_train_forward, or K / leading dimensions not multiples of 8)");
     if (stale_w) return fail("bf16 mode: a GEMM launch names a transposed operand that only exists as a bf16 image but cannot take the bf16 kernel (K / leading dimensions must be multiples of 8)");
     dim3 grid(((a.G + 7) / 8) * 8), block((big == 32 || big == 38) ? B16_THREADS : (big == 33 || big == 35 || big == 37) ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34 / 36: 256 = X3S_THREADS = H2S_THREADS)
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
@@ -580,6 +625,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_H2S_NS")) h->h2s_ns = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2_AIMG")) h->h2_aimg = atoi(e) != 0;
+    if (const char* e = getenv("VSR_FUSE")) h->fuse = atoi(e);
     if (const char* e = getenv("VSR_B16_DMA")) h->b16_dma = atoi(e) != 0;
     if (const char* e = getenv("VSR_ALIGNED_EFF")) h->aligned_eff_min = atoi(e) / 100.0;
     if (const char* e = getenv("VSR_X3S_SLOTS")) h->x3s_slots = std::max(1, atoi(e));
@@ -956,6 +1002,7 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     if (h2b && (size_t)(cdiv(prows, 4) + cdiv((long long)(indexed ? n_img : B) * R0, 4)) > c.scratch_floats) return fail("%s: scratch too small for the operand bounds", who);
     hipLaunchKernelGGL(k_rowmask, dim3(cdiv(prows, 4)), dim3(256), 0, s, regions, prows, D, c.bmask, bm_regions);
     HIPCHK(hipMemsetAsync(c.nvalid_dev, 0, 4 * sizeof(int), s));      // [0] row count, [1] bad slot indices, [2] bad word / slot / verb ids
+    HIPCHK(hipMemsetAsync(c.tickets, 0, (size_t)c.tickets_cap * sizeof(int), s));      // in-launch combine: every counter starts (and ends) a launch at zero
     if (indexed) {
         hipLaunchKernelGGL(k_index_rows, dim3(cdiv(rows, 256)), dim3(256), 0, s, slot_idx, row_img, c.bmask, B, L * R, Rb, n_img,
                            c.ridx_buf, c.rmask, c.nvalid_dev + 1);
@@ -1160,9 +1207,25 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[0].slab_stride = g.a.p[1].slab_stride = stride_a;
         g.a.p[2].C = c2b_base; g.a.p[3].C = c2b_base + D;
         g.a.p[2].slab_stride = g.a.p[3].slab_stride = stride_b;
+        // in-launch combine: the last arriver of a tile adds its k-pieces and finishes g_t (+ image) / hA / s_a / the sentinel itself;
+        // the attention kernel then starts at the scores (its slab phase - a third of its time - is gone)
+        bool f2 = (h->fuse & 1) && sh2;
+        for (int i = 0; i < 4 && f2; ++i) f2 = g.can_combine(i);
+        if (f2) {
+            GemmEpi e{};
+            e.kind = EPI_GT; e.ldo = H; e.isc = isc; e.o0 = c.g_t; e.o16 = g_t16; e.a0 = c.gpre; e.a1 = c1n;
+            g.a.p[0].epi = e;
+            e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = A; e.o0 = c.hA;
+            g.a.p[1].epi = e;
+            e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = D; e.o0 = c.sent; e.a0 = w.s_fc_bias; e.rpi = 1;      // (bias last: k_attend adds it to the slab sum)
+            g.a.p[2].epi = e;
+            e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = A; e.o0 = c.sa;
+            g.a.p[3].epi = e;
+            f2 = g.assign_tickets(c.tickets, c.tickets_cap);
+        }
         if (g.launch(s, h)) return fail("S2 gemm launch failed");
         // k_gate2's work (g_t, hA, s_a, sentinel from the S2 slabs) is done by the attention kernel's row blocks themselves
-        const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16, isc};
+        const Gate2Args g2{f2 ? nullptr : c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16, isc};
         const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
         if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
                            io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16, att_exp);
@@ -1184,14 +1247,29 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[0].slab_stride = stride;
         g.a.p[1].C = c.ga_slabs; g.a.p[1].slab_stride = stride_g;
         g.a.p[1].nslab = gemm_tight_slabs(g.a, 1);
+        // in-launch combine: LSTM2's logical columns are gate-interleaved (4 u + gate names weight row gate H + u), so a tile holds all four
+        // pre-activations of its 64 (32) hidden units and its last arriver runs the cell - k_lstm2 is not launched; att_ga's sums come as one matrix
+        bool f5 = (h->fuse & 2) && sh2 && g.can_combine(0) && g.can_combine(1);
+        if (f5) {
+            GemmEpi e{};
+            e.kind = EPI_LSTM2; e.rpi = io.rpi; e.isc = isc; e.o0 = h2n; e.o1 = c2n; e.o16 = h2n16; e.a0 = w.lstm2_bias_ih; e.a1 = w.lstm2_bias_hh;
+            e.a2 = d.img_second_lstm ? c.vproj2 : nullptr; e.a3 = c2o; e.idx = io.parent;
+            g.a.p[0].epi = e;
+            g.a.p[0].wperm_shift = 2; g.a.p[0].wperm_stride = H;
+            e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = A; e.o0 = c.ga;
+            g.a.p[1].epi = e;
+            f5 = g.assign_tickets(c.tickets, c.tickets_cap);
+        }
         if (g.launch(s, h)) return fail("S5 gemm launch failed");
-        hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
-                           w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n, h2n16, isc);
+        if (!f5)
+            hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
+                               w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n, h2n16, isc);
         // the gate logits (z_g, log_softmax([z_g, zsum]), step :185-188) are nobody's input before the selection: the
         // vocabulary kernel's row blocks compute them on the side instead of a launch of their own
         // (att_ga has a quarter of LSTM2's K: fewer stream-K pieces per tile, fewer slabs for the gate logits to add)
-        gate_args = GateLogitArgs{c.ga_slabs, g.a.p[1].nslab, stride_g, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A,
-                                  io.lg_out, io.lg_stride};
+        gate_args = f5 ? GateLogitArgs{c.ga, 1, 0, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A, io.lg_out, io.lg_stride}
+                       : GateLogitArgs{c.ga_slabs, g.a.p[1].nslab, stride_g, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A,
+                                       io.lg_out, io.lg_stride};
     }
     // ---- S6
     {
@@ -1226,9 +1304,25 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         c.pre1_ns = g.a.nprob > 1 ? ns_pre1 : ns; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
         // the vocabulary tiles (K = H) are cut into fewer pieces than the LSTM1 tiles (K = 2 H) they share the launch with: k_vocab
         // adds only the slabs they wrote (60 -> 40 MB of logits per beam-5 step)
-        const int ns_vocab = g.a.p[0].nslab = gemm_tight_slabs(g.a, 0);
+        int ns_vocab = g.a.p[0].nslab = gemm_tight_slabs(g.a, 0);
+        // in-launch combine: a tile's last arriver leaves (bias + slab 0 + slab 1 ...) - k_vocab's own order - in slab 0, and the LSTM1 / gate
+        // sums of the next step likewise: k_vocab and k_lstm1 read ONE slab each
+        bool f6 = (h->fuse & 4) && sh2;
+        for (int i = 0; i < g.a.nprob && f6; ++i) f6 = g.can_combine(i);
+        if (f6) {
+            GemmEpi e{};
+            e.kind = EPI_SUM; e.ldo = V; e.o0 = c.scratch; e.a0 = w.out_fc_bias; e.rpi = 0;       // (bias first: k_vocab starts from the bias)
+            g.a.p[0].epi = e;
+            for (int i = 1; i < g.a.nprob; ++i) {
+                e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = 6 * H; e.o0 = g.a.p[i].C;
+                g.a.p[i].epi = e;
+            }
+            f6 = g.assign_tickets(c.tickets, c.tickets_cap);
+            if (f6) { ns_vocab = 1; if (g.a.nprob > 1) c.pre1_ns = 1; }
+        }
+        const float* vocab_bias = f6 ? nullptr : w.out_fc_bias;
         if (g.launch(s, h)) return fail("S6 gemm launch failed");
-#define VOCAB_ARGS c.scratch, ns_vocab, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
+#define VOCAB_ARGS c.scratch, ns_vocab, stride, vocab_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
                    io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row, gate_args, c.nvalid_dev + 2
         const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;          // combined logits row staged in LDS (<= 96 KB)
         const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
