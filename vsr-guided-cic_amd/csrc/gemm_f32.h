@@ -42,38 +42,8 @@ struct GemmSeg {
     const uint16_t* A16; // bf16 kernel only, optional: a bf16 image of A (same rows, same lda) written by A's producer
 };
 
-// In-launch combine (the f16x2 kernels that implement it: gemm_h2a.h, the streaming kernel of gemm_h2.h; gemm_epi.h).  kind != 0: every piece
-// of a tile still writes its slab (write-through), then draws a ticket; the workgroup whose piece arrives LAST adds the tile's slabs in
-// index order - the order every consumer kernel adds them in, so the sums are bit-identical to the slab path's - and runs the
-// pointwise consumer of that GEMM on the spot.  The consumer kernel of the slab path (k_lstm2, the slab phase of k_attend, ...) is then
-// not launched, and the slabs are never read again.
-enum GemmEpiKind {
-    EPI_NONE = 0,
-    EPI_SUM = 1,      // out[m][n] = ((a0[n] +) slab 0 + slab 1 ...)                         a0: optional bias; out may be the problem's own slab 0
-    EPI_GT = 2,       // shift-gate vector: o0 = sigmoid(a0[m][n] + sum) * tanh(a1[m][n]) (+ image o16)      step :181-182   (k_attend's slab phase)
-    EPI_LSTM2 = 3,    // logical column 4 u + gate (GemmProb::wperm): LSTM2 cell of unit u (+ image o16)        step :176-177   (k_lstm2)
-};
-struct GemmEpi {
-    int kind;
-    int tick0;        // ticket of this problem's tile 0 (GemmArgs::tickets)
-    int ldo;          // leading dimension of o0 / o1 / a0 / a1 where they are (M, ldo) matrices
-    int rpi;          // EPI_LSTM2: rows per image (a2 = vproj2 is per image)
-    float isc;        // image kind / scale of o16 (kernels.h img_store)
-    float* o0;        // EPI_SUM: out; EPI_GT: g_t; EPI_LSTM2: h2 new
-    float* o1;        // EPI_LSTM2: c2 new
-    uint16_t* o16;    // optional image of o0
-    const float* a0;  // EPI_SUM: bias (N) or null; EPI_GT: gpre (M, ldo); EPI_LSTM2: b_ih (4 H)
-    const float* a1;  // EPI_GT: c1 new (M, ldo); EPI_LSTM2: b_hh (4 H)
-    const float* a2;  // EPI_LSTM2: vproj2 (images, 4 H) or null
-    const float* a3;  // EPI_LSTM2: c2 old (rows, H)
-    const int* idx;   // EPI_LSTM2: parent row of every row (c2 old is read through it) or null
-};
-
 struct GemmProb {
     GemmSeg seg[3];
-    GemmEpi epi;
-    int wperm_shift;     // 0: weight row = logical column n.  s > 0: logical column n names weight row (n & (2^s - 1)) * wperm_stride + (n >> s)
-    int wperm_stride;    // (2^s gate blocks of wperm_stride rows interleaved: the 2^s gates of one hidden unit are neighbours in a tile)
     float* C;            // (nslab, M, ldc)
     long long slab_stride;
     int nseg;
@@ -97,7 +67,6 @@ struct GemmArgs {
     int nslab;           // slabs per tile (S)
     int aligned;         // 0: stream-K ranges (gemm_plan); 1: one k-aligned piece of one tile per workgroup (gemm_plan_aligned)
     const int* exps;     // f16x2 kernels only: device table of scale exponents (GemmSeg::w_exp / a_exp index it)
-    int* tickets;        // in-launch combine: one arrival counter per tile of a problem with epi.kind != 0; all zero between launches (the last arriver resets its own)
 };
 
 // tile index -> tile origin: m fastest (the m-tiles of a weight n-tile are neighbours)

@@ -6,7 +6,6 @@
 // accumulators to the new unit at a segment boundary (a power of two: exact).
 #pragma once
 #include "gemm_h2.h"
-#include "gemm_epi.h"
 
 namespace vsr {
 
@@ -37,11 +36,11 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
     const int r = lane & 31, hh = lane >> 5;
 
     int cur_s = 0;                                         // multipliers: exponent of the products accumulated so far (2^cur_s units)
-    int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0, c_pieces = 1;     // c_pieces: k-pieces the current tile is cut into (in-launch combine)
+    int c_prob = 0, c_tile = 0, c_left = 0, c_piece = 0;
     bool c_last = false;
     auto decode = [&](int it) __attribute__((always_inline)) {
         if (args.aligned) {
-            c_prob = rg.prob; c_tile = rg.tile; c_piece = rg.piece; c_pieces = rg.split;
+            c_prob = rg.prob; c_tile = rg.tile; c_piece = rg.piece;
             c_left = it1 - it;
             c_last = rg.piece == rg.split - 1;
             return it - (args.p[rg.prob].it_begin + rg.tile * args.p[rg.prob].ktiles);
@@ -58,7 +57,6 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
         const int tile_base = it - kt;
         const int g_first = (int)((((long long)tile_base + 1) * G - 1) / args.total_iters);
         c_piece = g - g_first;
-        c_pieces = (int)((((long long)tile_base + P.ktiles) * G - 1) / args.total_iters) - g_first + 1;      // (workgroup of the tile's last k-tile)
         const int rem = P.ktiles - kt;
         c_left = rem < it1 - it ? rem : it1 - it;
         c_last = (c_left == rem);
@@ -75,8 +73,7 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
         const float unscale = h2_pow2(-cur_s);
         const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
         float* C = P.C + (long long)c_piece * P.slab_stride;
-        const bool combine = P.epi.kind != EPI_NONE;       // in-launch combine (gemm_epi.h): write-through slab stores, nobody reads an unused slab
-        const int extra = (c_last && !combine) ? P.nslab - 1 - c_piece : 0;
+        const int extra = c_last ? P.nslab - 1 - c_piece : 0;
         const bool vec_ok = ((P.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(P.C) & 15) == 0) && ((P.slab_stride & 3) == 0);
         constexpr int TPR = BN / 4;
         constexpr int RPP = H2_THREADS / TPR;
@@ -107,9 +104,7 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
                 if (sr < 32 && m < P.M && n < P.N) {
                     const float4 v = *reinterpret_cast<const float4*>(stage + sr * ST_LD + c4);
                     float* dst = C + (long long)m * P.ldc + n;
-                    if (combine) {
-                        st16_wt(dst, v);                   // (the host enables an epilogue only for 16-byte-aligned problems with N % 4 == 0)
-                    } else if (vec_ok && n + 3 < P.N) {
+                    if (vec_ok && n + 3 < P.N) {
                         *reinterpret_cast<float4*>(dst) = v;
                         for (int x = 1; x <= extra; ++x)
                             *reinterpret_cast<float4*>(dst + (long long)x * P.slab_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -126,10 +121,6 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
             __syncthreads();
         }
         wait_loads<0>();
-        if (combine) {
-            // the piece's slab is out (every wave has drained its stores): draw the tile's ticket; the last arriver adds the slabs and runs the consumer
-            if (gemm_epi_arrive(args.tickets + P.epi.tick0 + c_tile, c_pieces, s_exp + 8)) gemm_epi_tile<BM, BN, H2_THREADS>(P, m0, n0, c_pieces);
-        }
     };
     // k-tile number since it0 (its A buffer and A register set are j & 1, its W stage j % NW); end of a k-tile for BOTH kinds of waves.
     // A flush drains every wave's request queue first and uses the stage just multiplied from: the tiles already prefetched stay where
@@ -196,7 +187,6 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
                 for (int i = 0; i < LB; ++i) {
                     int n = n0 + 8 * (mw + 8 * i) + wr8;
                     n = n < P.N ? n : P.N - 1;
-                    if (P.wperm_shift) n = (n & ((1 << P.wperm_shift) - 1)) * P.wperm_stride + (n >> P.wperm_shift);      // gate-interleaved logical columns (GemmProb::wperm)
                     pbW[i] = S.W + (long long)n * S.ldw + wboff;       // the images have the fp32 matrices' byte geometry
                 }
 #pragma unroll

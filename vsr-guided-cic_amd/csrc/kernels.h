@@ -6,7 +6,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "pointwise.h"
 
 namespace vsr {
 
@@ -23,6 +22,49 @@ __device__ __forceinline__ float slab_sum(const float* __restrict__ p, int nslab
     for (int k = 0; k < 8; ++k)
         if (k < nslab) s += v[k];
     return s;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// bf16 image (round-to-nearest-even) of a value / of four consecutive values: the bf16 GEMM mode lets the producers of its A
+// operands write this image next to the fp32 value, so that the GEMM loads half the bytes and converts nothing
+__device__ __forceinline__ uint16_t bf16_bits(float x) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 v = {x, 0.f};
+    return (uint16_t)(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2)) & 0xffffu);
+}
+__device__ __forceinline__ uint2 bf16_bits4(float4 v) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    return make_uint2(__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, b2)), __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, b2)));
+}
+
+// Images of A operands for the GEMM kernels that take them (GemmSeg::A16), written by the producers next to the fp32 values.
+// isc == 0: bf16, 2 bytes per element (bf16 mode).  isc > 0: the f16x2 flavour's fp16 pairs of x * isc in the fp32 matrix's byte geometry
+// (gemm_h2a.h: both operands go global -> LDS by DMA, nothing is converted in the GEMM): elements [8 g, 8 g + 8) -> [hi x 8 | lo x 8],
+// `img` then addresses 2-byte units of a 4-byte-per-element buffer.  idx = row * ld + column with ld a multiple of 8.
+__device__ __forceinline__ void img_store(uint16_t* __restrict__ img, long long idx, float v, float isc) {
+    if (isc == 0.f) { img[idx] = bf16_bits(v); return; }
+    const float x = v * isc;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    uint16_t* g = img + ((idx >> 3) << 4) + (idx & 7);
+    g[0] = __builtin_bit_cast(uint16_t, hi);
+    g[8] = __builtin_bit_cast(uint16_t, lo);
+}
+__device__ __forceinline__ void img_store4(uint16_t* __restrict__ img, long long idx /* a multiple of 4 */, float4 v, float isc) {
+    if (isc == 0.f) { *reinterpret_cast<uint2*>(img + idx) = bf16_bits4(v); return; }
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 x = {v.x * isc, v.y * isc, v.z * isc, v.w * isc};
+    const h4 hi = __builtin_convertvector(x, h4);
+    const f4 rr = x - __builtin_convertvector(hi, f4);
+    const h4 lo = __builtin_convertvector(rr, h4);
+    uint16_t* g = img + ((idx >> 3) << 4) + (idx & 7);
+    *reinterpret_cast<uint2*>(g) = __builtin_bit_cast(uint2, hi);
+    *reinterpret_cast<uint2*>(g + 8) = __builtin_bit_cast(uint2, lo);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -411,8 +453,8 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                     if (k < g2.nsplit) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
                 if (c < H) {
                     float4 o;
-                    o.x = gt_cell(gp.x, s.x, cn.x); o.y = gt_cell(gp.y, s.y, cn.y);
-                    o.z = gt_cell(gp.z, s.z, cn.z); o.w = gt_cell(gp.w, s.w, cn.w);
+                    o.x = sigmoidf_(gp.x + s.x) * tanhf(cn.x); o.y = sigmoidf_(gp.y + s.y) * tanhf(cn.y);
+                    o.z = sigmoidf_(gp.z + s.z) * tanhf(cn.z); o.w = sigmoidf_(gp.w + s.w) * tanhf(cn.w);
                     *reinterpret_cast<float4*>(g2.g_t + (long long)row * H + c) = o;
                     if (g2.g_t16) img_store4(g2.g_t16, (long long)row * H + c, o, g2.isc);
                 } else {
@@ -604,8 +646,8 @@ __global__ void k_lstm2(const float* __restrict__ pre, int nsplit, long long str
         q[g] = s;
     }
     const int prow = parent ? parent[row] : row;
-    float c, h2v;
-    lstm_cell(q[0], q[1], q[2], q[3], c2_old[(long long)prow * H + j], h2v, c);
+    const float c = sigmoidf_(q[1]) * c2_old[(long long)prow * H + j] + sigmoidf_(q[0]) * tanhf(q[2]);
+    const float h2v = sigmoidf_(q[3]) * tanhf(c);
     h2n[i] = h2v;
     c2n[i] = c;
     if (h2n16) img_store(h2n16, i, h2v, isc);
@@ -677,7 +719,7 @@ __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { retur
 
 enum VocabMode { VM_TOPK = 0, VM_SAMPLE = 1, VM_FORCED = 2, VM_FULL = 3 };
 
-// Per row: logits = bias + sum of slabs (bias == nullptr: the GEMM launch has combined bias and slabs itself, gemm_epi.h); log-sum-exp; then by mode
+// Per row: logits = sum of slabs + bias; log-sum-exp; then by mode
 //   VM_TOPK   K best (log-prob, id) pairs (K = 1: greedy arg-max)          (CaptioningModel.py:47, :152)
 //   VM_SAMPLE Gumbel-max draw from Categorical(logits) + its log-prob      (:66-70)
 //   VM_FORCED log-prob of a given id (sampling replay)
@@ -726,7 +768,7 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
                 // logit - lse > -1e6 <=> always true for finite logits: first strict maximum wins
                 for (int q = vt_ptr[verb]; q < vt_ptr[verb + 1]; ++q) {
                     const int id = vt_ids[q];
-                    float x = bias ? bias[id] : 0.f;
+                    float x = bias[id];
                     for (int k = 0; k < nsplit; ++k) x += src[k * stride + id];
                     if (pick < 0 || x > best) { best = x; pick = id; }
                 }
@@ -769,7 +811,7 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
             for (int u = 0; u < VU; ++u) {
                 const int v0 = vb + 4 * NT * u;
                 const bool in = v0 < V4;
-                part[u][0] = (in && bias) ? *reinterpret_cast<const float4*>(bias + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                part[u][0] = in ? *reinterpret_cast<const float4*>(bias + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < KU; ++k)
                     part[u][k + 1] = (in && k < nsplit) ? *reinterpret_cast<const float4*>(src + k * stride + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -796,7 +838,7 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
                     const int v = vb + 4 * NT * u + e;
                     float x = 0.f;
                     if (v < V) {
-                        x = bias ? bias[v] : 0.f;
+                        x = bias[v];
                         for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
                     }
                     xs_all[u][e] = x;
@@ -833,7 +875,7 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
 
     auto getx = [&](int v) {
         if (use_lds) return lrow[v];
-        float x = bias ? bias[v] : 0.f;
+        float x = bias[v];
         for (int k = 0; k < nsplit; ++k) x += src[k * stride + v];
         return x;
     };

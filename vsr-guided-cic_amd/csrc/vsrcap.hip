@@ -82,9 +82,6 @@ struct Ctx {
     uint16_t* st16[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     uint16_t *s_t16 = nullptr, *g_t16 = nullptr, *att16 = nullptr;
     bool st16_ok[2] = {false, false};
-    int* tickets = nullptr;      // in-launch combine (gemm_epi.h): arrival counters of a launch's tiles; all zero between launches
-    int tickets_cap = 0;
-    float* ga = nullptr;         // att_ga(g_t) sums when the LSTM2 launch combines them itself (M, A)
     float* pre1 = nullptr;       // LSTM1/gate sums of the NEXT step, produced early (merged with the vocabulary GEMM)
     int pre1_ns = 0, pre1_nblk = 0;
     long long pre1_stride = 0;
@@ -121,10 +118,6 @@ struct vsr_handle {
     // and launches whose A operands all have one take the all-DMA kernel (gemm_h2a.h); VSR_H2_AIMG=0: in-kernel split of fp32 A only
     double aligned_eff_min = 0.75;    // wide launches: k-aligned pieces when they keep at least this share of the CUs busy, stream-K ranges otherwise (VSR_ALIGNED_EFF, percent)
     bool h2_aimg = true;
-    // in-launch combine of the k-pieces with the pointwise consumer as the last arriver's epilogue (gemm_epi.h), all-DMA kernel only.
-    // VSR_FUSE bits: 1 = S2 (g_t, hA, s_a, sentinel: k_attend's slab phase), 2 = S5 (LSTM2 cell: k_lstm2; att_ga sums), 4 = S6 (the
-    // vocabulary logits and the next step's LSTM1 sums reach k_vocab / k_lstm1 as ONE slab)
-    int fuse = 7;
     bool b16_dma = true;              // bf16 mode: launches whose A operands all have bf16 images take the all-DMA kernel (VSR_B16_DMA=0: register-staged)
     int h2a_max_small = 128;          // launches of at most this many rows (and more than h2s_max) : 128 x 128 tiles of the all-DMA kernel
     std::vector<H2Range> h2t;         // the training pass's transposed operands (vsr_train_forward registers the images of its workspace)
@@ -281,9 +274,6 @@ static size_t carve(const vsr_handle* h, Ctx& c, char* base) {
     c.scratch_floats = std::max(stage * 8, std::max(rows, prows) * A * 8);   // att_va slabs of prepare(): over the bank rows when indexed
     c.scratch = b.take<float>(c.scratch_floats);
     c.pre1 = b.take<float>(M * 6 * H * 8);
-    c.ga = b.take<float>(M * A);
-    c.tickets_cap = (int)(((M + 127) / 128) * ((6 * H + (H + A) + (D + A) + 4 * H + A + V) / 128 + 16));     // >= the tiles of any one launch (128-wide tiles)
-    c.tickets = b.take<int>((size_t)c.tickets_cap);
     b.off = (b.off + 15) & ~size_t(15);
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j) c.st16[i][j] = b.take<uint16_t>(2 * ((M * H + 7) & ~size_t(7)));      // (bf16: 2 bytes per element; fp16 pairs: 4)
@@ -506,24 +496,6 @@ struct GemmBuilder {
         // tiles are cut into ~3 stream-K pieces instead of ~5, so every consumer kernel reads 40 % fewer slab bytes.
         return gemm_plan(a, big ? h->gemm_slots / 2 : h->gemm_slots_small, h->gemm_min_iters, big ? 128 : 64, big == 2 ? 128 : 64);
     }
-    // In-launch combine: the launch takes the all-DMA kernel and problem i is 16-byte clean (N, ldc, slab stride multiples of 4, aligned
-    // base).  Call after finish() and after the caller has set C / slab_stride.
-    bool can_combine(int i) const {
-        const GemmProb& p = a.p[i];
-        return big == 37 && (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.slab_stride % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
-    }
-    // hand the problems with an epilogue their ticket ranges; false (and every epilogue off) when the counters do not suffice
-    bool assign_tickets(int* tickets, int cap) {
-        int t = 0;
-        for (int i = 0; i < a.nprob; ++i)
-            if (a.p[i].epi.kind != EPI_NONE) { a.p[i].epi.tick0 = t; t += a.p[i].tiles_m * a.p[i].tiles_n; }
-        if (t > cap) {
-            for (int i = 0; i < a.nprob; ++i) { a.p[i].epi.kind = EPI_NONE; a.p[i].wperm_shift = 0; }
-            return false;
-        }
-        a.tickets = tickets;
-        return true;
-    }
     int launch(hipStream_t s, vsr_handle* h);
 };
 
@@ -625,7 +597,6 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_H2S_NS")) h->h2s_ns = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2_AIMG")) h->h2_aimg = atoi(e) != 0;
-    if (const char* e = getenv("VSR_FUSE")) h->fuse = atoi(e);
     if (const char* e = getenv("VSR_B16_DMA")) h->b16_dma = atoi(e) != 0;
     if (const char* e = getenv("VSR_ALIGNED_EFF")) h->aligned_eff_min = atoi(e) / 100.0;
     if (const char* e = getenv("VSR_X3S_SLOTS")) h->x3s_slots = std::max(1, atoi(e));
@@ -1002,7 +973,6 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     if (h2b && (size_t)(cdiv(prows, 4) + cdiv((long long)(indexed ? n_img : B) * R0, 4)) > c.scratch_floats) return fail("%s: scratch too small for the operand bounds", who);
     hipLaunchKernelGGL(k_rowmask, dim3(cdiv(prows, 4)), dim3(256), 0, s, regions, prows, D, c.bmask, bm_regions);
     HIPCHK(hipMemsetAsync(c.nvalid_dev, 0, 4 * sizeof(int), s));      // [0] row count, [1] bad slot indices, [2] bad word / slot / verb ids
-    HIPCHK(hipMemsetAsync(c.tickets, 0, (size_t)c.tickets_cap * sizeof(int), s));      // in-launch combine: every counter starts (and ends) a launch at zero
     if (indexed) {
         hipLaunchKernelGGL(k_index_rows, dim3(cdiv(rows, 256)), dim3(256), 0, s, slot_idx, row_img, c.bmask, B, L * R, Rb, n_img,
                            c.ridx_buf, c.rmask, c.nvalid_dev + 1);
@@ -1207,25 +1177,9 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[0].slab_stride = g.a.p[1].slab_stride = stride_a;
         g.a.p[2].C = c2b_base; g.a.p[3].C = c2b_base + D;
         g.a.p[2].slab_stride = g.a.p[3].slab_stride = stride_b;
-        // in-launch combine: the last arriver of a tile adds its k-pieces and finishes g_t (+ image) / hA / s_a / the sentinel itself;
-        // the attention kernel then starts at the scores (its slab phase - a third of its time - is gone)
-        bool f2 = (h->fuse & 1) && sh2;
-        for (int i = 0; i < 4 && f2; ++i) f2 = g.can_combine(i);
-        if (f2) {
-            GemmEpi e{};
-            e.kind = EPI_GT; e.ldo = H; e.isc = isc; e.o0 = c.g_t; e.o16 = g_t16; e.a0 = c.gpre; e.a1 = c1n;
-            g.a.p[0].epi = e;
-            e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = A; e.o0 = c.hA;
-            g.a.p[1].epi = e;
-            e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = D; e.o0 = c.sent; e.a0 = w.s_fc_bias; e.rpi = 1;      // (bias last: k_attend adds it to the slab sum)
-            g.a.p[2].epi = e;
-            e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = A; e.o0 = c.sa;
-            g.a.p[3].epi = e;
-            f2 = g.assign_tickets(c.tickets, c.tickets_cap);
-        }
         if (g.launch(s, h)) return fail("S2 gemm launch failed");
         // k_gate2's work (g_t, hA, s_a, sentinel from the S2 slabs) is done by the attention kernel's row blocks themselves
-        const Gate2Args g2{f2 ? nullptr : c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16, isc};
+        const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16, isc};
         const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
         if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
                            io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16, att_exp);
@@ -1247,29 +1201,14 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         g.a.p[0].slab_stride = stride;
         g.a.p[1].C = c.ga_slabs; g.a.p[1].slab_stride = stride_g;
         g.a.p[1].nslab = gemm_tight_slabs(g.a, 1);
-        // in-launch combine: LSTM2's logical columns are gate-interleaved (4 u + gate names weight row gate H + u), so a tile holds all four
-        // pre-activations of its 64 (32) hidden units and its last arriver runs the cell - k_lstm2 is not launched; att_ga's sums come as one matrix
-        bool f5 = (h->fuse & 2) && sh2 && g.can_combine(0) && g.can_combine(1);
-        if (f5) {
-            GemmEpi e{};
-            e.kind = EPI_LSTM2; e.rpi = io.rpi; e.isc = isc; e.o0 = h2n; e.o1 = c2n; e.o16 = h2n16; e.a0 = w.lstm2_bias_ih; e.a1 = w.lstm2_bias_hh;
-            e.a2 = d.img_second_lstm ? c.vproj2 : nullptr; e.a3 = c2o; e.idx = io.parent;
-            g.a.p[0].epi = e;
-            g.a.p[0].wperm_shift = 2; g.a.p[0].wperm_stride = H;
-            e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = A; e.o0 = c.ga;
-            g.a.p[1].epi = e;
-            f5 = g.assign_tickets(c.tickets, c.tickets_cap);
-        }
         if (g.launch(s, h)) return fail("S5 gemm launch failed");
-        if (!f5)
-            hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
-                               w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n, h2n16, isc);
+        hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
+                           w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n, h2n16, isc);
         // the gate logits (z_g, log_softmax([z_g, zsum]), step :185-188) are nobody's input before the selection: the
         // vocabulary kernel's row blocks compute them on the side instead of a launch of their own
         // (att_ga has a quarter of LSTM2's K: fewer stream-K pieces per tile, fewer slabs for the gate logits to add)
-        gate_args = f5 ? GateLogitArgs{c.ga, 1, 0, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A, io.lg_out, io.lg_stride}
-                       : GateLogitArgs{c.ga_slabs, g.a.p[1].nslab, stride_g, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A,
-                                       io.lg_out, io.lg_stride};
+        gate_args = GateLogitArgs{c.ga_slabs, g.a.p[1].nslab, stride_g, c.hA, w.att_g_weight, c.zsum, io.verbs, io.slot, io.rpi, c.L, M, A,
+                                  io.lg_out, io.lg_stride};
     }
     // ---- S6
     {
@@ -1304,25 +1243,9 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         c.pre1_ns = g.a.nprob > 1 ? ns_pre1 : ns; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
         // the vocabulary tiles (K = H) are cut into fewer pieces than the LSTM1 tiles (K = 2 H) they share the launch with: k_vocab
         // adds only the slabs they wrote (60 -> 40 MB of logits per beam-5 step)
-        int ns_vocab = g.a.p[0].nslab = gemm_tight_slabs(g.a, 0);
-        // in-launch combine: a tile's last arriver leaves (bias + slab 0 + slab 1 ...) - k_vocab's own order - in slab 0, and the LSTM1 / gate
-        // sums of the next step likewise: k_vocab and k_lstm1 read ONE slab each
-        bool f6 = (h->fuse & 4) && sh2;
-        for (int i = 0; i < g.a.nprob && f6; ++i) f6 = g.can_combine(i);
-        if (f6) {
-            GemmEpi e{};
-            e.kind = EPI_SUM; e.ldo = V; e.o0 = c.scratch; e.a0 = w.out_fc_bias; e.rpi = 0;       // (bias first: k_vocab starts from the bias)
-            g.a.p[0].epi = e;
-            for (int i = 1; i < g.a.nprob; ++i) {
-                e = GemmEpi{}; e.kind = EPI_SUM; e.ldo = 6 * H; e.o0 = g.a.p[i].C;
-                g.a.p[i].epi = e;
-            }
-            f6 = g.assign_tickets(c.tickets, c.tickets_cap);
-            if (f6) { ns_vocab = 1; if (g.a.nprob > 1) c.pre1_ns = 1; }
-        }
-        const float* vocab_bias = f6 ? nullptr : w.out_fc_bias;
+        const int ns_vocab = g.a.p[0].nslab = gemm_tight_slabs(g.a, 0);
         if (g.launch(s, h)) return fail("S6 gemm launch failed");
-#define VOCAB_ARGS c.scratch, ns_vocab, stride, vocab_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
+#define VOCAB_ARGS c.scratch, ns_vocab, stride, w.out_fc_bias, M, V, io.vmode, c.top_v, c.top_i, io.full_out, io.full_stride, io.forced, \
                    io.seed, (uint32_t)io.t, io.verbs, io.slot, io.rpi, c.L, io.gt, h->vt_ptr, h->vt_ids, h->n_verbs, lds_row, gate_args, c.nvalid_dev + 2
         const int lds_row = V <= VOCAB_LDS_MAX ? 1 : 0;          // combined logits row staged in LDS (<= 96 KB)
         const size_t vsm = lds_row ? (size_t)V * sizeof(float) : 0;
