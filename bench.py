@@ -302,6 +302,7 @@ def decode_bench(args, D, torch, dist, synth):
     lo, hi = parallel.shard_bounds(c["B"], world, rank) if strong else (0, c["B"])
     # two distinct resident batches, alternated, so no step can reuse the previous step's prepare()
     batches = []
+    valid_rows = 0
     for i in range(2):
         seed = 1000 + i + (0 if strong else 10 * rank)
         if indexed:
@@ -311,8 +312,12 @@ def decode_bench(args, D, torch, dist, synth):
             idx = torch.from_numpy(synth.make_slot_indices(c["B"], c["L"], c["R"], c["R0"], seed=seed)[lo:hi]).contiguous().to(dev)
             batches.append((det, IndexedRegions(det, idx)))
         else:
+            ctrl_np = synth.make_ctrl(c["B"], c["L"], c["R"], c["D"], seed=seed)[lo:hi]
+            valid_rows = max(valid_rows, int((ctrl_np.sum(-1) != 0).sum()))       # known on the host, like the eval script's own tensors
             batches.append((torch.from_numpy(synth.make_detections(c["B"], c["R0"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev),
-                            torch.from_numpy(synth.make_ctrl(c["B"], c["L"], c["R"], c["D"], seed=seed)[lo:hi]).contiguous().to(dev)))
+                            torch.from_numpy(ctrl_np).contiguous().to(dev)))
+    if args.rows_bound and valid_rows > 0:
+        m.set_valid_rows_bound(valid_rows)      # vsr_prepare() then never waits for the host (include/vsrcap.h, vsr_set_valid_rows_bound)
 
     def one_step(i):
         det, ctrl = batches[i & 1]
@@ -358,6 +363,7 @@ def decode_bench(args, D, torch, dist, synth):
                    "beam": beam, "batch_per_gpu": hi - lo, "seq_len": c["T"],
                    "parallelism": "images sharded, dp%d%s" % (world, ", ids all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else "gloo self-test") if strong else ", no data-path collective"),
                    "rccl_world_size_observed": D.observed_world(), "collective_backend": args.backend,
+                   "host_sync_per_call": "none (caller-supplied bound on the non-padding region rows)" if (args.rows_bound and valid_rows > 0) else "one 8-byte read-back in vsr_prepare (the number of non-padding region rows)",
                    "decode_cache": "prebuilt, weight-only (embedding rows through the x columns of the LSTM1 / gate input weights, "
                                    "240 MB, built once per weight version outside the timed call; all per-image hoisting is inside)"},
         "roofline": roofline_block(args.dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic, tsrc, gemm_bytes),
@@ -542,6 +548,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=12)
     ap.add_argument("--cpu-full", type=int, default=1, help="1: the CPU baseline's value is ONE as-written call at the workload's own batch size (0: the bounded sample only)")
     ap.add_argument("--batch", type=int, default=0, help="images per batch instead of 100 (experiments only: not the BASELINE workload)")
+    ap.add_argument("--rows-bound", action="store_true", help="decode workloads with dense regions: hand the library the host-known number of non-padding region rows "
+                                                              "(model.set_valid_rows_bound): the decode call then has no host synchronisation at all")
     ap.add_argument("--emit-ids", action="store_true", help="decode workloads: put the (B, T) word ids of the last timed step into config.ids (tests compare a sharded run with a single-process run)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL, one GPU per rank (the measurement); gloo = self-test of the multi-rank path on fewer GPUs than ranks")

@@ -169,6 +169,12 @@ size_t vsr_workspace_bytes_indexed(const vsr_handle* h, int32_t B, int32_t R0, i
 int vsr_prepare_indexed(vsr_handle* h, const float* det, int32_t n_img, int32_t R0, const float* bank, int32_t Rb,
                         const int32_t* row_img, int32_t B, const int32_t* slot_idx, int32_t L, int32_t R, int32_t beam,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* vsr_prepare*() projects only the NON-PADDING region rows (att_va(0) = 0) and needs their number to size that launch: by default the
+ * count is read back (the one place where the library waits for the device).  A caller that knows an upper bound - eval_coco.py:222-237
+ * builds det_seqs_recons on the host, train.py's loader pads on the host - passes it here (sticky; 0 = back to the read-back): the
+ * following vsr_prepare*() calls then never synchronise (the row list is padded to the bound on the device).  Rows beyond the bound get
+ * no projection; their number is added to vsr_bad_ids()'s count (as are bad slot indices of the index-list format in this mode). */
+int vsr_set_valid_rows_bound(vsr_handle* h, int64_t max_valid_rows);
 /* mask[i] = (sum_d rows[i, :] != 0), the reference's zero-row test (controllable_captioning.py:126,159) */
 int vsr_row_mask(const float* rows, int64_t n_rows, int32_t D, float* mask, void* stream);
 /* eval_coco.py:222-241 on index lists, N captions at once:
@@ -203,7 +209,7 @@ int vsr_xe_forward(vsr_handle* h, const int64_t* captions, int32_t T, float* log
  * Word ids outside [0, V) (nn.Embedding raises on them, controllable_captioning.py:144), slot traces outside [0, L),
  * replayed gates outside {0, 1} and gt-verb ids outside [0, V) (step_v :280) are CLAMPED on the device - never an
  * out-of-bounds access - and counted.  *count = ids clamped by the calls since the last vsr_prepare*() or vsr_bad_ids();
- * the call synchronises the stream and resets the counter. */
+ * the call synchronises the stream and resets the counter.  (With vsr_set_valid_rows_bound: plus the region rows beyond the bound.) */
 int vsr_bad_ids(vsr_handle* h, int32_t* count, void* stream);
 
 /* ---- single timestep (ControllableCaptioningModel.step / step_v :117-297), feedback mode ---------- */

@@ -17,10 +17,14 @@ TOOL = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 
 @pytest.mark.parametrize("variant", ["1 1", "121 1", "2 2", "1605 2", "1607 2", "1664 1", "1665 1", "1664 21", "1665 21", "3300 1", "3300 21",
                                      "3400 1",           # the weight-streaming f32x3 kernel (<= 128 rows, k-aligned pieces only)
-                                     "5200 1", "5200 21", "5300 1", "5400 1", "5400 21", "1666 1", "1666 21"])
+                                     "5200 1", "5200 21", "5300 1", "5400 1", "5400 21",
+                                     "5400 21 nw4",      # ... the 128 x 128 all-DMA tile with a DMA ring of four stages (the product's default for <= 128 rows)
+                                     "1666 1", "1666 21"])
 def test_gemm_variant_on_random_ragged_launches(variant):
     if not os.path.exists(TOOL):
         pytest.skip("tools/gemm_bench not built (python vsr-guided-cic_amd/build.py --tool, or __graft_entry__.build())")
-    r = subprocess.run([TOOL, "fuzz"] + variant.split() + ["16", "5"], capture_output=True, text=True, timeout=600)
+    v = variant.split()
+    env = dict(os.environ, H2_NW="4") if v[-1] == "nw4" else dict(os.environ)
+    r = subprocess.run([TOOL, "fuzz"] + v[:2] + ["16", "5"], capture_output=True, text=True, timeout=600, env=env)
     tail = "\n".join(r.stdout.splitlines()[-20:])
     assert r.returncode == 0 and "0 of 16 cases failed" in r.stdout, tail + r.stderr[-2000:]

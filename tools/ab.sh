@@ -2,7 +2,7 @@
 # One-call A/B on the GPU box: an optional parity gate, then bench.py values for a list of environment settings, repeated.
 #   tools/ab.sh <tag> [-g "<pytest args>"] [-w "<workloads>"] [-r <repeats>] [-s <steps>] "<ENV=..;ENV=..>" ["<ENV=..>" ...]
 # e.g. tools/ab.sh r05a -g "tests/test_gpu_headline.py" -w "beam5 greedy b13" "VSR_FUSE=1" "VSR_FUSE=0"
-# Workloads: beam5 greedy xe scst b13 (= beam5 --batch 13) xe_real beam5_eval.  Every configuration runs inside THIS call (boxes of the
+# Workloads: beam5 greedy xe scst b13 (= beam5 --batch 13) xe_real beam5_eval; b13nb / beam5nb / greedynb = the same with --rows-bound (no host sync in prepare).  Every configuration runs inside THIS call (boxes of the
 # pool differ by up to 10 %: only same-call pairs are compared).  Replaces round 4's 22 single-use tools/r04*.sh (git log -- tools/).
 TAG=$1; shift
 GATE=""; WL="beam5 greedy b13"; REP=2; STEPS=30
@@ -16,7 +16,7 @@ if [ -n "$GATE" ]; then
   grep -q "passed" $OUT/gate.txt && ! grep -q "failed\|error" $OUT/gate.txt || echo "GATE FAILED (timings below are of a build that does not pass)"
 fi
 for rep in $(seq 1 $REP); do for cfg in "$@"; do for w in $WL; do
-  case $w in b13) args="--workload beam5 --batch 13";; *) args="--workload $w";; esac
+  case $w in b13) args="--workload beam5 --batch 13";; b13nb) args="--workload beam5 --batch 13 --rows-bound";; beam5nb) args="--workload beam5 --rows-bound";; greedynb) args="--workload greedy --rows-bound";; *) args="--workload $w";; esac
   env $(echo "$cfg" | tr ';' ' ') timeout 400 python bench.py $args --steps $STEPS --warmup 5 --no-cpu --no-secondary --no-alt 2>$OUT/last.err | tail -1 | python3 -c "
 import sys, json
 try:

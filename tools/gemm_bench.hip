@@ -184,7 +184,9 @@ struct Builder {
 #undef H2S
         }
         else if (tm == 5400) {
-            if (tn == 21) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1, 3>), g, dim3(H2_THREADS), 0, st, a);
+            const int nw = getenv("H2_NW") ? atoi(getenv("H2_NW")) : 3;         // ring stages of the 128 x 128 tile (the 128 x 256 tile has room for three)
+            if (tn == 21 && nw == 4) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1, 4>), g, dim3(H2_THREADS), 0, st, a);
+            else if (tn == 21) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1, 3>), g, dim3(H2_THREADS), 0, st, a);
             else hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 2, 3>), g, dim3(H2_THREADS), 0, st, a);
         }
         else if (tm == 5200) {

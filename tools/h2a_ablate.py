@@ -15,10 +15,7 @@ d = "/tmp/h2aabl"
 shutil.rmtree(d, ignore_errors=True)
 os.makedirs(d + "/vsr-guided-cic_amd")
 shutil.copytree(ROOT + "/vsr-guided-cic_amd/csrc", d + "/vsr-guided-cic_amd/csrc")
-os.makedirs(d + "/tools")
-for f in os.listdir(ROOT + "/tools"):
-    if f.endswith((".hip", ".h")):
-        shutil.copy(ROOT + "/tools/" + f, d + "/tools/" + f)
+shutil.copytree(ROOT + "/tools", d + "/tools", ignore=lambda p, names: [n for n in names if not (n.endswith((".hip", ".h")) or n == "experiments")])
 p = d + "/vsr-guided-cic_amd/csrc/gemm_h2a.h"
 s = open(p).read()
 def rep(old, new, cnt=1):
@@ -43,6 +40,6 @@ rep("        wait_loads<0>();\n        __syncthreads();                         
     "        wait_loads<0>();\n        __syncthreads();                                   // ... for every wave's requests: nothing lands in `stage` from here on\n        if constexpr (abl == 6) {\n            if constexpr (decltype(MULT)::value) {\n                _Pragma(\"unroll\") for (int ti = 0; ti < TM; ++ti) _Pragma(\"unroll\") for (int tj = 0; tj < TN; ++tj) _Pragma(\"unroll\") for (int e = 0; e < 16; ++e) asm volatile(\"\" :: \"v\"(acc[ti][tj][e]));\n            }\n            return;\n        }\n")
 open(p, "w").write(s)
 b = d + "/tools/gemm_bench.hip"
-procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-DH2A_ABL=%d" % n, "-o", ROOT + "/tools/gemm_bench_abl%d" % n, b]) for n in (0, 6)]
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-DH2A_ABL=%d" % n, "-o", ROOT + "/tools/gemm_bench_abl%d" % n, b]) for n in (0, 1, 2, 3, 4, 6)]
 assert all(p.wait() == 0 for p in procs)
-print("built tools/gemm_bench_abl0, _abl6 (edit the tuple above for the others)")
+print("built tools/gemm_bench_abl0..4, 6")

@@ -82,6 +82,46 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
         const int wm = wave / WN, wn = wave % WN;
         wait_loads<0>();
         __syncthreads();                                   // ... for every wave's requests: nothing lands in `stage` from here on
+        if (args.aligned) {
+            // k-aligned plan: this piece is the workgroup's only one, nothing is prefetched behind it, the whole ring is free: stage all 128
+            // rows at once - two barriers instead of eight, every thread's stores back to back (the flush is 3 of a skinny launch's 23 us)
+            static_assert(BM * ST_LD * 4 <= NW * STG * 2, "whole-tile staging must fit the ring");
+            float* const all = reinterpret_cast<float*>(sW);
+            if constexpr (decltype(MULT)::value) {
+#pragma unroll
+                for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < TN; ++tj)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            all[(32 * (wm * TM + ti) + (e & 3) + 8 * (e >> 2) + 4 * hh) * ST_LD + wn * (32 * TN) + tj * 32 + r] = acc[ti][tj][e] * unscale;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < BM / RPP; ++i) {
+                const int sr = tid / TPR + RPP * i;
+                const int m = m0 + sr;
+                if (m < P.M && n < P.N) {
+                    const float4 v = *reinterpret_cast<const float4*>(all + sr * ST_LD + c4);
+                    float* dst = C + (long long)m * P.ldc + n;
+                    if (vec_ok && n + 3 < P.N) {
+                        *reinterpret_cast<float4*>(dst) = v;
+                        for (int x = 1; x <= extra; ++x)
+                            *reinterpret_cast<float4*>(dst + (long long)x * P.slab_stride) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < P.N) {
+                                dst[q] = vv[q];
+                                for (int x = 1; x <= extra; ++x) dst[(long long)x * P.slab_stride + q] = 0.f;
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+            wait_loads<0>();
+            return;
+        }
 #pragma unroll
         for (int band = 0; band < BM / 32; ++band) {
             if (m0 + band * 32 >= P.M) break;
@@ -216,15 +256,18 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
             int st = 0;
             for (int n = 0; n < NW - 1 && it0 + n < it1; ++n) { issue(st); ++st; }
         }
-        if (NW >= 3 && it0 + 1 < it1) wait_loads<(NW - 2) * (LA + LB)>(); else wait_loads<0>();      // (NW = 3: k-tile 0 has landed, k-tile 1 may be in flight)
+        // (a full prologue of NW - 1 k-tiles: k-tile 0 has landed once at most the NW - 2 younger ones are in flight; a shorter one: drain)
+        if (NW >= 3 && it0 + NW - 2 < it1) wait_loads<(NW - 2) * (LA + LB)>(); else wait_loads<0>();
         __syncthreads();                                   // k-tile 0 is ready
-        // k-tile j: issue k-tile j + NW - 1 into the stage the last barrier freed; wait until k-tile j + 1 has landed; barrier
-        static_assert(NW == 3, "the counted waits below are written for a ring of three");
+        // k-tile j: issue k-tile j + NW - 1 into the stage the last barrier freed; wait until k-tile j + 1 has landed (at most the NW - 2
+        // k-tiles behind it in flight); barrier.  (NW = 4 fits the 128 x 128 tile and was measured: no gain - profiles/r05_e_*; at M = 100 the
+        // launch is 23 us of which the k loop without any DMA is 19.5 and with idle multipliers 18.9 - profiles/r05_d_*: fixed cost and MFMA time)
+        static_assert(NW == 3 || NW == 4, "the counted waits below are written for rings of three / four");
         while (it < it1) {
             int st = ws + NW - 1;
             st = st >= NW ? st - NW : st;
             const bool more = it + NW - 1 < it1;
-            if (more) { issue(st); wait_loads<LA + LB>(); } else wait_loads<0>();
+            if (more) { issue(st); wait_loads<(NW - 2) * (LA + LB)>(); } else wait_loads<0>();
             end_of_ktile(std::false_type{});
         }
     } else {

@@ -252,10 +252,25 @@ __global__ __launch_bounds__(256) void k_compact_write(const float* __restrict__
     if (v) vlist[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
 }
 
+// Caller-supplied bound on the non-padding rows (vsr_set_valid_rows_bound): the list is padded up to `bound` entries with its first row
+// (the projection GEMM is sized by the bound, the scatter below stops at the real count, which never leaves the device).
+// counts: [0] rows found, [1] bad slot indices of the index-list format, [2] the bad-id counter, [3] rows beyond the bound (reported by vsr_bad_ids)
+__global__ void k_pad_row_list(int* __restrict__ vlist, int* __restrict__ counts, int bound) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = counts[0];
+    if (i == 0) {
+        if (n > bound) counts[3] = n - bound;
+        if (counts[1] != 0) atomicAdd(counts + 2, counts[1]);
+    }
+    if (i >= n && i < bound) vlist[i] = n > 0 ? vlist[0] : 0;
+}
+
 // P[vlist[m]] = sum of the slabs' row m   (scatter of the compact projection back to the dense row index)
+// rows_dev (optional): the number of real rows lives on the device (the launch covers `rows` = the caller's bound)
 __global__ void k_slab_reduce_scatter(const float* __restrict__ slabs, int nslab, long long stride, int rows, int A,
-                                      const int* __restrict__ vlist, float* __restrict__ P) {
+                                      const int* __restrict__ vlist, float* __restrict__ P, const int* __restrict__ rows_dev = nullptr) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (rows_dev && *rows_dev < rows) rows = *rows_dev;
     if (i >= (long long)rows * A) return;
     const int m = (int)(i / A), a = (int)(i % A);
     float s = slab_sum(slabs + i, nslab, stride);

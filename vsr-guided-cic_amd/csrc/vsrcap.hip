@@ -119,6 +119,8 @@ struct vsr_handle {
     double aligned_eff_min = 0.75;    // wide launches: k-aligned pieces when they keep at least this share of the CUs busy, stream-K ranges otherwise (VSR_ALIGNED_EFF, percent)
     bool h2_aimg = true;
     bool b16_dma = true;              // bf16 mode: launches whose A operands all have bf16 images take the all-DMA kernel (VSR_B16_DMA=0: register-staged)
+    int h2a_skinny_nw = 3;            // DMA ring stages of the 128 x 128 tile of the all-DMA kernel (VSR_H2A_NW=3|4).  A fourth stage changes nothing (profiles/r05_e_*: 72.6 vs 73.8 us over the
+                                      // step GEMMs at M = 100, greedy 703-709 k vs 699 k tokens/s): its k loop is MFMA-bound (24 MFMAs per SIMD and 32-k tile = 0.5 us at the clock it holds), the rest of a 23 us launch is fixed cost
     int h2a_max_small = 128;          // launches of at most this many rows (and more than h2s_max) : 128 x 128 tiles of the all-DMA kernel
     std::vector<H2Range> h2t;         // the training pass's transposed operands (vsr_train_forward registers the images of its workspace)
     const H2Range* map_h2(const float* p, bool with_train = true) const {
@@ -189,6 +191,7 @@ struct vsr_handle {
     int gemm_aligned = 1;        // 128 x 256 kernels: k-aligned pieces (gemm_plan_aligned) when the tiles fit the CUs; VSR_GEMM_ALIGNED=0: stream-K always
     int gemm_aligned_min = 8;    // shortest piece, in 64-wide k-tiles (VSR_GEMM_ALIGNED_MIN)
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
+    long long rows_bound = 0;    // vsr_set_valid_rows_bound: > 0 = the caller's upper bound on the non-padding region rows; vsr_prepare*() then never waits for the host
     int gemm_tile = 0;           // 0 = by M; VSR_GEMM_TILE=64 | 12864 | 128 forces 64x64 / 128x64 / 128x128
     Ctx c;
     // measurement
@@ -515,7 +518,8 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     } else if (big == 38 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_b16a_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 38) hipLaunchKernelGGL((gemm_nt_b16a_kernel<2, 1>), grid, block, 0, s, a);
     else if (big == 37 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 2>), grid, block, 0, s, a);
-    else if (big == 37) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1>), grid, block, 0, s, a);
+    else if (big == 37 && h->h2a_skinny_nw == 4) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1, 4>), grid, block, 0, s, a);
+    else if (big == 37) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1, 3>), grid, block, 0, s, a);
     else if (big == 35 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 35) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 1>), grid, block, 0, s, a);
     else if (big == 34) {
@@ -597,6 +601,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_H2S_NS")) h->h2s_ns = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2_AIMG")) h->h2_aimg = atoi(e) != 0;
+    if (const char* e = getenv("VSR_H2A_NW")) h->h2a_skinny_nw = atoi(e) == 4 ? 4 : 3;
     if (const char* e = getenv("VSR_B16_DMA")) h->b16_dma = atoi(e) != 0;
     if (const char* e = getenv("VSR_ALIGNED_EFF")) h->aligned_eff_min = atoi(e) / 100.0;
     if (const char* e = getenv("VSR_X3S_SLOTS")) h->x3s_slots = std::max(1, atoi(e));
@@ -908,6 +913,13 @@ extern "C" int vsr_set_gemm_mode(vsr_handle* h, int32_t mode) {
     return 0;
 }
 
+extern "C" int vsr_set_valid_rows_bound(vsr_handle* h, int64_t max_valid_rows) {
+    if (!h) return fail("vsr_set_valid_rows_bound: null handle");
+    if (max_valid_rows < 0) return fail("vsr_set_valid_rows_bound: negative bound");
+    h->rows_bound = max_valid_rows;
+    return 0;
+}
+
 extern "C" int vsr_set_verb_table(vsr_handle* h, const int32_t* row_ptr, const int32_t* vocab_ids, int32_t n_verbs) {
     if (!h) return fail("vsr_set_verb_table: null handle");
     h->vt_ptr = row_ptr;
@@ -984,11 +996,20 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
         hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, s, c.bmask, (int)prows, c.bcount, c.vlist);
     }
     LAUNCHCHK();
-    if (!h->host_back) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->host_back), 2 * sizeof(int), hipHostMallocDefault));
-    int* back = h->host_back;                                            // pinned: the copy does not block this thread
-    HIPCHK(hipMemcpyAsync(back, c.nvalid_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-    if (!h->ev_count) HIPCHK(hipEventCreateWithFlags(&h->ev_count, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(h->ev_count, s));
+    // A caller that knows an upper bound on the non-padding rows (vsr_set_valid_rows_bound: the eval script builds its region tensors on
+    // the host and has the count for free) gets NO read-back: the list is padded to the bound on the device, the projection is sized by it.
+    const long long bound = h->rows_bound > 0 ? std::min(h->rows_bound, prows) : 0;
+    int* back = nullptr;
+    if (bound > 0) {
+        hipLaunchKernelGGL(k_pad_row_list, dim3(cdiv(bound, 256)), dim3(256), 0, s, c.vlist, c.nvalid_dev, (int)bound);
+        LAUNCHCHK();
+    } else {
+        if (!h->host_back) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->host_back), 2 * sizeof(int), hipHostMallocDefault));
+        back = h->host_back;                                             // pinned: the copy does not block this thread
+        HIPCHK(hipMemcpyAsync(back, c.nvalid_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (!h->ev_count) HIPCHK(hipEventCreateWithFlags(&h->ev_count, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(h->ev_count, s));
+    }
 
     // pooled descriptor
     const long long drows = (long long)(indexed ? n_img : B) * R0;
@@ -1033,9 +1054,13 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
         hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.vproj2);
         LAUNCHCHK();
     }
-    HIPCHK(hipEventSynchronize(h->ev_count));
-    c.nvalid = back[0];
-    if (indexed && back[1] != 0) return fail("%s: %d slot entries index outside the feature bank [-1, %d) or name an image outside [0, %d)", who, back[1], Rb, n_img);
+    if (bound > 0) {
+        c.nvalid = (int)bound;         // (bad slot indices of the index-list format join the bad-id count: vsr_bad_ids)
+    } else {
+        HIPCHK(hipEventSynchronize(h->ev_count));
+        c.nvalid = back[0];
+        if (indexed && back[1] != 0) return fail("%s: %d slot entries index outside the feature bank [-1, %d) or name an image outside [0, %d)", who, back[1], Rb, n_img);
+    }
     if (c.nvalid > 0) {
         GemmBuilder g;
         g.keep_fp32 = true;
@@ -1047,7 +1072,8 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
             return fail("%s: att_va slabs (%lld x %d floats) exceed the workspace scratch (%zu)", who, stride, ns, c.scratch_floats);
         g.a.p[0].slab_stride = stride;
         if (g.launch(s, h)) return fail("att_va gemm launch failed");
-        hipLaunchKernelGGL(k_slab_reduce_scatter, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.nvalid, A, c.vlist, c.P);
+        hipLaunchKernelGGL(k_slab_reduce_scatter, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, c.nvalid, A, c.vlist, c.P,
+                           bound > 0 ? c.nvalid_dev : (const int*)nullptr);
         LAUNCHCHK();
     }
     h->prepared = true;
@@ -1300,11 +1326,11 @@ extern "C" int vsr_bad_ids(vsr_handle* h, int32_t* count, void* stream) {
     if (!h || !count) return fail("vsr_bad_ids: null argument");
     if (!h->prepared) { *count = 0; return 0; }
     hipStream_t s = (hipStream_t)stream;
-    int v = 0;
-    HIPCHK(hipMemcpyAsync(&v, h->c.nvalid_dev + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    int v[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(v, h->c.nvalid_dev + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(hipMemsetAsync(h->c.nvalid_dev + 2, 0, sizeof(int), s));
-    *count = v;
+    HIPCHK(hipMemsetAsync(h->c.nvalid_dev + 2, 0, 2 * sizeof(int), s));
+    *count = v[0] + v[1];              // [1]: non-padding region rows beyond the caller's bound (vsr_set_valid_rows_bound) - they got no projection
     return 0;
 }
 

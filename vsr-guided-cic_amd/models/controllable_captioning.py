@@ -89,6 +89,9 @@ class ControllableCaptioningModel(CaptioningModel):
         # set force_prepare = True when inputs / weights are rewritten in ways that do not bump _version
         # (t.data.copy_, DLPack / custom-kernel writes, p.data edits), or call invalidate_cache() after such a write
         self.force_prepare = False
+        # set_valid_rows_bound(): the caller's upper bound on the non-padding region rows of the NEXT calls (None: the library counts them
+        # and reads the count back, its one host synchronisation per call)
+        self.valid_rows_bound = None
         # VSR_COMPUTE_DTYPE lets a whole test run (or an unchanged reference script) select the GEMM flavour without code changes
         self.compute_dtype = os.environ.get('VSR_COMPUTE_DTYPE', DEFAULT_COMPUTE_DTYPE)
 
@@ -102,6 +105,15 @@ class ControllableCaptioningModel(CaptioningModel):
         if dtype not in COMPUTE_DTYPES:
             raise ValueError("compute dtype must be one of %s" % (COMPUTE_DTYPES,))
         self.compute_dtype = dtype
+        return self
+
+    def set_valid_rows_bound(self, n):
+        """Extension (not in the reference): an upper bound on the rows of the region tensor that are not zero padding - for index lists,
+        on the non-zero rows of the feature bank - which a caller that builds its inputs on the host (coco_scripts/eval_coco.py:222-237,
+        data/field.py:44-61) has for free.  The decode / training calls then never wait for the device (include/vsrcap.h,
+        vsr_set_valid_rows_bound).  None switches back to the device-side count + read-back.  A bound that is too small is reported by
+        the next input-contract check (rows beyond it would get no att_va projection)."""
+        self.valid_rows_bound = None if n is None else int(n)
         return self
 
     def invalidate_cache(self):
@@ -176,8 +188,8 @@ class ControllableCaptioningModel(CaptioningModel):
         vsrcap.regions.IndexedRegions (index lists into the image's feature bank; training too when every row is its own image)."""
         from vsrcap.regions import IndexedRegions
         if isinstance(regions, IndexedRegions):
-            return eng.prepare_indexed(det, regions.bank, regions.slot_idx, regions.row_img, beam, self._weights_version())
-        return eng.prepare(det, regions, beam, self._weights_version())
+            return eng.prepare_indexed(det, regions.bank, regions.slot_idx, regions.row_img, beam, self._weights_version(), self.valid_rows_bound)
+        return eng.prepare(det, regions, beam, self._weights_version(), self.valid_rows_bound)
 
     # ------------------------------------------------------------------ loops (CaptioningModel hooks)
     def _run_forward(self, statics, seqs):

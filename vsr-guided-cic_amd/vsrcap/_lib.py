@@ -94,6 +94,7 @@ SIGNATURES = {
     "vsr_train_bucket_map": (I32, [C.POINTER(I32), C.POINTER(I32)]),
     "vsr_train_wait_bucket": (I32, [P, I32, P]),
     "vsr_bad_ids": (I32, [P, C.POINTER(I32), P]),
+    "vsr_set_valid_rows_bound": (I32, [P, I64]),
     "vsr_debug_copy": (I32, [P, C.c_char_p, P, SZ, P]),
     "vsr_cider_rewards": (I32, [P, P, P, C.c_double, P, I32, I32, P, I32, I32, I64, I64, P, I32, C.c_double, P, P]),
     "vsr_ssp_create": (I32, [C.POINTER(P)]),

@@ -108,7 +108,8 @@ class Engine:
         n = C.c_int32(0)
         _lib.check(self.lib.vsr_bad_ids(self.h, C.byref(n), self._stream(device)))
         if n.value:
-            raise IndexError("%s: %d word / slot / verb ids out of range (clamped on the device; nn.Embedding would raise)" % (who, n.value))
+            raise IndexError("%s: %d word / slot / verb ids out of range (clamped on the device; nn.Embedding would raise) or region rows beyond "
+                             "the caller's set_valid_rows_bound() (they got no att_va projection)" % (who, n.value))
 
     @_on_device
     def set_verb_table(self, table, device):
@@ -194,7 +195,9 @@ class Engine:
 
     # ------------------------------------------------------------------ hoisted statics
     @_on_device
-    def prepare(self, det, regions, beam, weights_version=None):
+    def prepare(self, det, regions, beam, weights_version=None, rows_bound=None):
+        """rows_bound: an upper bound on the non-padding region rows the caller knows on the host (None: the library reads the
+        count back - its one synchronisation; include/vsrcap.h, vsr_set_valid_rows_bound)"""
         det = _f32(det, "detections")
         regions = _f32(regions, "region sequences")
         if det.dim() != 3 or regions.dim() != 4 or det.size(0) != regions.size(0) or det.size(2) != regions.size(3):
@@ -204,9 +207,10 @@ class Engine:
         B, R0, _ = det.shape
         _, L, R, _ = regions.shape
         key = (det.data_ptr(), det._version, regions.data_ptr(), regions._version, B, R0, L, R, beam,
-               self._bound_ptrs, weights_version)
+               self._bound_ptrs, weights_version, rows_bound)
         if key == self._prep_key:
             return B
+        _lib.check(self.lib.vsr_set_valid_rows_bound(self.h, int(rows_bound or 0)))
         need = self.lib.vsr_workspace_bytes(self.h, B, R0, L, R, beam)
         if need == 0:
             raise RuntimeError("vsr_workspace_bytes rejected the shapes")
@@ -220,7 +224,7 @@ class Engine:
         return B
 
     @_on_device
-    def prepare_indexed(self, det, bank, slot_idx, row_img, beam, weights_version=None):
+    def prepare_indexed(self, det, bank, slot_idx, row_img, beam, weights_version=None, rows_bound=None):
         """Index-list region format (include/vsrcap.h, vsr_prepare_indexed): det (n_img,R0,D), bank (n_img,Rb,D),
         slot_idx (B,L,R) int32 rows of the row's image bank (-1 = padding), row_img (B) int32 or None."""
         det = _f32(det, "detections")
@@ -245,9 +249,10 @@ class Engine:
             row_img = row_img.contiguous()
         key = ("idx", det.data_ptr(), det._version, bank.data_ptr(), bank._version, slot_idx.data_ptr(), slot_idx._version,
                None if row_img is None else (row_img.data_ptr(), row_img._version), B, n_img, R0, Rb, L, R, beam,
-               self._bound_ptrs, weights_version)
+               self._bound_ptrs, weights_version, rows_bound)
         if key == self._prep_key:
             return B
+        _lib.check(self.lib.vsr_set_valid_rows_bound(self.h, int(rows_bound or 0)))
         need = self.lib.vsr_workspace_bytes_indexed(self.h, B, R0, n_img, Rb, L, R, beam)
         if need == 0:
             raise RuntimeError("vsr_workspace_bytes_indexed rejected the shapes")
