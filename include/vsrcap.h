@@ -13,7 +13,8 @@
  *     int64 / int32 exactly as the reference lays them out (weights: [out, in]).
  *   - all work is enqueued on the caller's hipStream_t (passed as void*); no call synchronises the host, with ONE
  *     exception: vsr_prepare() reads back a single integer (the number of non-padding region rows, which sizes the
- *     hoisted att_va GEMM) and therefore waits for the stream once.
+ *     hoisted att_va GEMM) and therefore waits for the stream once - unless the caller has given an upper bound on that
+ *     number (vsr_set_valid_rows_bound): then no call of the data path waits.
  *   - the library allocates nothing on the launch path: the caller provides one workspace of
  *     vsr_workspace_bytes() bytes (16-byte aligned) that must stay untouched between vsr_prepare() and
  *     the decode / forward calls that use it.

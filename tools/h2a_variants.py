@@ -7,6 +7,7 @@ untouched, so results are the shipped kernel's (gemm_bench checks them against f
   2  ... s_sleep 4 between requests
   3  A requests first, then W (shipped: W first)
   4  movers at lower priority than the multipliers (s_setprio 0 / 3)
+  5  the flush of round 4: band by band through one W stage also on k-aligned plans (shipped since round 5: the whole tile staged at once)
 usage: tools/h2a_variants.py ; then tools/gemm_bench_var<n> 500 256 4 5400 1"""
 import os, shutil, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,8 +51,9 @@ rep("        int seg_exp = 0;\n", "        int seg_exp = 0;\n        bool spread
 rep("        __syncthreads();                                   // k-tile 0 is ready\n        // k-tile j: issue k-tile j + NW - 1",
     "        __syncthreads();                                   // k-tile 0 is ready\n        spread = true;\n        if constexpr (var == 4) __builtin_amdgcn_s_setprio(0);\n        // k-tile j: issue k-tile j + NW - 1")
 rep("        zero_acc();\n        bool first = true;\n", "        zero_acc();\n        bool first = true;\n        if constexpr (var == 4) __builtin_amdgcn_s_setprio(3);\n")
+rep("        if (args.aligned) {\n            // k-aligned plan: this piece is the workgroup's only one", "        if (args.aligned && var != 5) {\n            // k-aligned plan: this piece is the workgroup's only one")
 open(p, "w").write(s)
 b = d + "/tools/gemm_bench.hip"
-procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-DH2A_VAR=%d" % n, "-o", ROOT + "/tools/gemm_bench_var%d" % n, b]) for n in (0, 1, 2, 3, 4)]
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-DH2A_VAR=%d" % n, "-o", ROOT + "/tools/gemm_bench_var%d" % n, b]) for n in (0, 1, 2, 3, 4, 5)]
 assert all(p.wait() == 0 for p in procs)
-print("built tools/gemm_bench_var0..4")
+print("built tools/gemm_bench_var0..5")
