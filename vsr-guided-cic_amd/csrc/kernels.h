@@ -334,6 +334,20 @@ __global__ void k_i32_to_i64(const int* src, int64_t* dst, int n) {
 // pre: (nsplit, M, 6H) raw GEMM sums of [h2 | x | h1_old]; vproj: (B, 6H) hoisted vbar part + biases.
 // xproj (optional): (V, 6H) cached projection of every embedding row (decode cache), gathered by word[row];
 // nblk: number of leading gate blocks (of 6) that the GEMM produced (the rest only has hoisted terms).
+// the cell itself: q = [i, f, g, o, s-gate, g-gate image part] pre-activations of one (row, unit)
+__device__ __forceinline__ void lstm1_point(const float (&q)[6], float c_old, long long i, float* __restrict__ h1n, float* __restrict__ c1n,
+                                            float* __restrict__ s_t, float* __restrict__ gpre, uint16_t* __restrict__ h1n16,
+                                            uint16_t* __restrict__ s_t16, float isc) {
+    const float c = sigmoidf_(q[1]) * c_old + sigmoidf_(q[0]) * tanhf(q[2]);
+    const float tc = tanhf(c);
+    const float h1v = sigmoidf_(q[3]) * tc, stv = sigmoidf_(q[4]) * tc;
+    h1n[i] = h1v;
+    c1n[i] = c;
+    s_t[i] = stv;
+    gpre[i] = q[5];
+    if (h1n16) { img_store(h1n16, i, h1v, isc); img_store(s_t16, i, stv, isc); }
+}
+
 __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long stride, const float* __restrict__ vproj,
                         int rpi, const int* __restrict__ parent, const float* __restrict__ c1_old, int M, int H,
                         float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre,
@@ -355,15 +369,7 @@ __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long str
         if (xp) s += xp[(long long)g * H];
         q[g] = s + vp[(long long)g * H];
     }
-    const float c_old = c1_old[(long long)prow * H + j];
-    const float c = sigmoidf_(q[1]) * c_old + sigmoidf_(q[0]) * tanhf(q[2]);
-    const float tc = tanhf(c);
-    const float h1v = sigmoidf_(q[3]) * tc, stv = sigmoidf_(q[4]) * tc;
-    h1n[i] = h1v;
-    c1n[i] = c;
-    s_t[i] = stv;
-    gpre[i] = q[5];
-    if (h1n16) { img_store(h1n16, i, h1v, isc); img_store(s_t16, i, stv, isc); }
+    lstm1_point(q, c1_old[(long long)prow * H + j], i, h1n, c1n, s_t, gpre, h1n16, s_t16, isc);
 }
 
 // reduce the slabs of h1 -> [W1_hg | att_ha] and s_t -> [s_fc | att_sa]; finish the shift-gate vector
@@ -1071,49 +1077,91 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
 
 // ---------------------------------------------------------------------------------------------- selection
 // greedy / sampling / replay: next word and gate per row, advance the slot pointer     (:47, :66-70, step :135-140)
-__global__ void k_select_simple(int mode, const float* __restrict__ top_v, const int* __restrict__ top_i,
-                                const float* __restrict__ lg, const int* __restrict__ forced_gate, uint64_t seed,
-                                uint32_t t, const int* __restrict__ slot, int L, int M, int T,
-                                int* __restrict__ word_next, int* __restrict__ gate_next, int* __restrict__ slot_next,
-                                int64_t* __restrict__ words, int64_t* __restrict__ gates, float* __restrict__ lp_w,
-                                float* __restrict__ lp_g) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= M) return;
-    const float l0 = lg[row * 2], l1 = lg[row * 2 + 1];
+struct SelSimpleArgs {
+    int mode; const float* top_v; const int* top_i; const float* lg; const int* forced_gate; uint64_t seed; uint32_t t;
+    const int* slot; int L, M, T;
+    int* word_next; int* gate_next; int* slot_next; int64_t* words; int64_t* gates; float* lp_w; float* lp_g;
+};
+// one row's selection; `write`: this thread stores the row's outputs.  Returns the word.
+__device__ __forceinline__ int select_simple_row(const SelSimpleArgs& a, int row, bool write) {
+    const float l0 = a.lg[row * 2], l1 = a.lg[row * 2 + 1];
     int g;
-    if (mode == VM_TOPK) g = (l1 > l0) ? 1 : 0;                       // torch.max: first maximum on ties
-    else if (mode == VM_FORCED) g = forced_gate[row];
+    if (a.mode == VM_TOPK) g = (l1 > l0) ? 1 : 0;                       // torch.max: first maximum on ties
+    else if (a.mode == VM_FORCED) g = a.forced_gate[row];
     else {
         uint32_t rnd[4];
-        Philox::gen(seed, 0xFFFFFFFFu, (uint32_t)row, t, 1u, rnd);
+        Philox::gen(a.seed, 0xFFFFFFFFu, (uint32_t)row, a.t, 1u, rnd);
         g = (Philox::u01(rnd[0]) < expf(l0)) ? 0 : 1;
     }
-    const int w = top_i[row];
-    word_next[row] = w;
-    gate_next[row] = g;
-    int k = slot[row] + g;
-    slot_next[row] = k < 0 ? 0 : (k > L - 1 ? L - 1 : k);
-    words[(long long)row * T + t] = w;
-    gates[(long long)row * T + t] = g;
-    if (lp_w) lp_w[(long long)row * T + t] = top_v[row];
-    if (lp_g) lp_g[(long long)row * T + t] = g ? l1 : l0;
+    const int w = a.top_i[row];
+    if (write) {
+        a.word_next[row] = w;
+        a.gate_next[row] = g;
+        int k = a.slot[row] + g;
+        a.slot_next[row] = k < 0 ? 0 : (k > a.L - 1 ? a.L - 1 : k);
+        a.words[(long long)row * a.T + a.t] = w;
+        a.gates[(long long)row * a.T + a.t] = g;
+        if (a.lp_w) a.lp_w[(long long)row * a.T + a.t] = a.top_v[row];
+        if (a.lp_g) a.lp_g[(long long)row * a.T + a.t] = g ? l1 : l0;
+    }
+    return w;
+}
+__global__ void k_select_simple(const SelSimpleArgs a) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= a.M) return;
+    select_simple_row(a, row, true);
+}
+
+// k_select_simple of step t - 1 inside k_lstm1 of step t (round 5): the selection is per row and a handful of operations, so every
+// thread of the LSTM1 kernel redoes its row's (the one with unit 0 stores it) instead of a 6 us launch of its own in front of it.
+// Same arithmetic as the two kernels it replaces (select_simple_row, lstm1_point).  Greedy / sampling / replay; rows are their own parents.
+__global__ void k_select_simple_lstm1(const SelSimpleArgs sel, const float* __restrict__ pre, int nsplit, long long stride,
+                                      const float* __restrict__ vproj, const float* __restrict__ c1_old, int M, int H,
+                                      float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre,
+                                      const float* __restrict__ xproj, int nblk, uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16,
+                                      float isc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)M * H) return;
+    const int row = (int)(i / H), j = (int)(i % H);
+    const long long base = (long long)row * 6 * H + j;
+    const float* vp = vproj + (long long)row * 6 * H + j;
+    // the slab sums do not depend on the selection: their loads are in flight while it is made
+    float q[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) q[g] = g < nblk ? slab_sum(pre + base + (long long)g * H, nsplit, stride) : 0.f;
+    const int w = select_simple_row(sel, row, j == 0);
+    const float* xp = xproj + (long long)w * 6 * H + j;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        float s = q[g];
+        s += xp[(long long)g * H];
+        q[g] = s + vp[(long long)g * H];
+    }
+    lstm1_point(q, c1_old[(long long)row * H + j], i, h1n, c1n, s_t, gpre, h1n16, s_t16, isc);
 }
 
 // joint (word x gate) beam selection, one wave per image                       (CaptioningModel.py:136-180)
 // candidates: cb beams x K best words x 2 gates; score = seq + (lw + lg) in that association.
+struct SelBeamArgs {
+    int t, cb, beam, L; int64_t eos_w, eos_g;
+    const float* top_v; const int* top_i; const float* lg; const int* slot; const int* word_prev; const int* gate_prev;
+    const float* seq_in; float* seq_out; const float* mask_in; float* mask_out;
+    int* word_next; int* gate_next; int* slot_next; int* parent_row;
+    int* hist_parent; int* hist_word; int* hist_gate; float* hist_lpw; float* hist_lpg; int B;
+};
+// one wave selects the `beam` survivors of image b.  write: store them (one caller per image does); sel_s (optional, LDS):
+// [q] = the survivor's parent beam j, [KMAX + q] = its word - for a caller that goes on with the survivors itself.
 template <int K>
-__global__ __launch_bounds__(64) void k_select_beam(int t, int cb, int beam, int L, int64_t eos_w, int64_t eos_g,
-                                                    const float* __restrict__ top_v, const int* __restrict__ top_i,
-                                                    const float* __restrict__ lg, const int* __restrict__ slot,
-                                                    const int* __restrict__ word_prev, const int* __restrict__ gate_prev,
-                                                    const float* __restrict__ seq_in, float* __restrict__ seq_out,
-                                                    const float* __restrict__ mask_in, float* __restrict__ mask_out,
-                                                    int* __restrict__ word_next, int* __restrict__ gate_next,
-                                                    int* __restrict__ slot_next, int* __restrict__ parent_row,
-                                                    int* __restrict__ hist_parent, int* __restrict__ hist_word,
-                                                    int* __restrict__ hist_gate, float* __restrict__ hist_lpw,
-                                                    float* __restrict__ hist_lpg, int B) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void select_beam_wave(const SelBeamArgs& a, int b, int lane, bool write, int* sel_s) {
+    const int t = a.t, cb = a.cb, beam = a.beam, L = a.L, B = a.B;
+    const int64_t eos_w = a.eos_w, eos_g = a.eos_g;
+    const float* __restrict__ top_v = a.top_v; const int* __restrict__ top_i = a.top_i; const float* __restrict__ lg = a.lg;
+    const int* __restrict__ slot = a.slot; const int* __restrict__ word_prev = a.word_prev; const int* __restrict__ gate_prev = a.gate_prev;
+    const float* __restrict__ seq_in = a.seq_in; const float* __restrict__ mask_in = a.mask_in;
+    float* __restrict__ seq_out = a.seq_out; float* __restrict__ mask_out = a.mask_out;
+    int* __restrict__ word_next = a.word_next; int* __restrict__ gate_next = a.gate_next; int* __restrict__ slot_next = a.slot_next;
+    int* __restrict__ parent_row = a.parent_row; int* __restrict__ hist_parent = a.hist_parent; int* __restrict__ hist_word = a.hist_word;
+    int* __restrict__ hist_gate = a.hist_gate; float* __restrict__ hist_lpw = a.hist_lpw; float* __restrict__ hist_lpg = a.hist_lpg;
     const int ncand = cb * K * 2;
     // each lane owns up to 2 candidates (ncand <= 128) and loads everything a winner will have to write with them: the selection
     // rounds below are shuffles only (a winner that went back to memory for its log-probs paid up to K dependent round trips)
@@ -1172,24 +1220,72 @@ __global__ __launch_bounds__(64) void k_select_beam(int t, int cb, int beam, int
             const int u = bl & 1;
             const int j = cj[u], w = cw[u], g = cg[u];
             const int orow = b * beam + q, prow = b * cb + j;
-            seq_out[orow] = bv;
-            word_next[orow] = w;
-            gate_next[orow] = g;
-            parent_row[orow] = prow;
-            slot_next[orow] = ck[u];
-            mask_out[orow * 2] = cmw[u];
-            mask_out[orow * 2 + 1] = cmg[u];
-            const long long hrow = (long long)t * B * beam + orow;
-            hist_parent[hrow] = j;
-            hist_word[hrow] = w;
-            hist_gate[hrow] = g;
-            // returned per-slot log-probs: log-prob of the selection, zeroed once its stream saw EOS
-            hist_lpw[hrow] = clw[u] * cmw[u];
-            hist_lpg[hrow] = clg[u] * cmg[u];
+            if (sel_s) { sel_s[q] = j; sel_s[KMAX + q] = w; }
+            if (write) {
+                seq_out[orow] = bv;
+                word_next[orow] = w;
+                gate_next[orow] = g;
+                parent_row[orow] = prow;
+                slot_next[orow] = ck[u];
+                mask_out[orow * 2] = cmw[u];
+                mask_out[orow * 2 + 1] = cmg[u];
+                const long long hrow = (long long)t * B * beam + orow;
+                hist_parent[hrow] = j;
+                hist_word[hrow] = w;
+                hist_gate[hrow] = g;
+                // returned per-slot log-probs: log-prob of the selection, zeroed once its stream saw EOS
+                hist_lpw[hrow] = clw[u] * cmw[u];
+                hist_lpg[hrow] = clg[u] * cmg[u];
+            }
             cv[u] = -INFINITY;
             cflat[u] = 0x7fffffffffffffffLL;
         }
     }
+}
+template <int K>
+__global__ __launch_bounds__(64) void k_select_beam(const SelBeamArgs a) { select_beam_wave<K>(a, blockIdx.x, threadIdx.x, true, nullptr); }
+
+// k_select_beam of step t - 1 inside k_lstm1 of step t (round 5).  One workgroup per (image, slice of SL_UB = 64 hidden units) of
+// (beam + 1) waves: the last wave makes the image's selection (every slice's workgroup makes it - it is one wave's work - slice 0 stores
+// it) WHILE wave p < cb adds the LSTM1 / gate slabs of the image's PARENT row p for the slice's units (the sums do not depend on the
+// selection; a child row reads its parent's) into LDS; then wave q is CHILD row q: its parent's sums from LDS, its word's cached
+// embedding projection, the image's hoisted terms - the expressions and their order are k_lstm1's (slab_sum, + xproj, + vproj,
+// lstm1_point), and every (row, unit) element is one thread's work as there.  (A first version gave a thread all five rows of a unit:
+// five dependent rounds of loads instead of one - slower than the two launches it replaced, profiles/r05_f_*.)
+constexpr int SL_UB = 64;
+template <int K>
+__global__ __launch_bounds__((K + 1) * 64) void k_select_lstm1(const SelBeamArgs sel, const float* __restrict__ pre, int nsplit, long long stride,
+                                                               const float* __restrict__ vproj, const float* __restrict__ c1_old, int H, int nslice,
+                                                               float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t,
+                                                               float* __restrict__ gpre, const float* __restrict__ xproj, int nblk,
+                                                               uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16, float isc) {
+    __shared__ float sums[K * 6 * SL_UB];
+    __shared__ int sel_s[2 * KMAX];
+    const int b = blockIdx.x / nslice, slice = blockIdx.x % nslice;
+    const int wave = threadIdx.x >> 6, u = threadIdx.x & 63, cb = sel.cb;
+    const int j = slice * SL_UB + u;
+    if (wave == K) {
+        select_beam_wave<K>(sel, b, u, slice == 0, sel_s);
+    } else if (wave < cb && j < H) {
+        const long long base = (long long)(b * cb + wave) * 6 * H + j;
+#pragma unroll
+        for (int g = 0; g < 6; ++g)
+            sums[(wave * 6 + g) * SL_UB + u] = g < nblk ? slab_sum(pre + base + (long long)g * H, nsplit, stride) : 0.f;
+    }
+    __syncthreads();
+    if (wave == K || j >= H) return;
+    const int pl = sel_s[wave], w = sel_s[KMAX + wave];
+    const int row = b * K + wave, prow = b * cb + pl;
+    const float* vp = vproj + (long long)b * 6 * H + j;
+    const float* xp = xproj + (long long)w * 6 * H + j;
+    float q[6];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        float s = sums[(pl * 6 + g) * SL_UB + u];
+        s += xp[(long long)g * H];
+        q[g] = s + vp[(long long)g * H];
+    }
+    lstm1_point(q, c1_old[(long long)prow * H + j], (long long)row * H + j, h1n, c1n, s_t, gpre, h1n16, s_t16, isc);
 }
 
 // final ordering by sequence log-prob + back-tracking through the parent pointers      (:182-194)

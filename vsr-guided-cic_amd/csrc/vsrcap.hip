@@ -118,6 +118,8 @@ struct vsr_handle {
     // and launches whose A operands all have one take the all-DMA kernel (gemm_h2a.h); VSR_H2_AIMG=0: in-kernel split of fp32 A only
     double aligned_eff_min = 0.75;    // wide launches: k-aligned pieces when they keep at least this share of the CUs busy, stream-K ranges otherwise (VSR_ALIGNED_EFF, percent)
     bool h2_aimg = true;
+    // the selection of step t inside the LSTM1 kernel of step t + 1 (kernels.h: k_select_lstm1, k_select_simple_lstm1); VSR_FUSE_SELECT=0: a launch of its own
+    int fuse_select = 3;              // bit 0: greedy / sampling / replay (k_select_simple_lstm1), bit 1: beam search (k_select_lstm1)
     bool b16_dma = true;              // bf16 mode: launches whose A operands all have bf16 images take the all-DMA kernel (VSR_B16_DMA=0: register-staged)
     int h2a_skinny_nw = 3;            // DMA ring stages of the 128 x 128 tile of the all-DMA kernel (VSR_H2A_NW=3|4).  A fourth stage changes nothing (profiles/r05_e_*: 72.6 vs 73.8 us over the
                                       // step GEMMs at M = 100, greedy 703-709 k vs 699 k tokens/s): its k loop is MFMA-bound (24 MFMAs per SIMD and 32-k tile = 0.5 us at the clock it holds), the rest of a 23 us launch is fixed cost
@@ -601,6 +603,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_H2S_NS")) h->h2s_ns = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2_AIMG")) h->h2_aimg = atoi(e) != 0;
+    if (const char* e = getenv("VSR_FUSE_SELECT")) h->fuse_select = atoi(e);
     if (const char* e = getenv("VSR_H2A_NW")) h->h2a_skinny_nw = atoi(e) == 4 ? 4 : 3;
     if (const char* e = getenv("VSR_B16_DMA")) h->b16_dma = atoi(e) != 0;
     if (const char* e = getenv("VSR_ALIGNED_EFF")) h->aligned_eff_min = atoi(e) / 100.0;
@@ -1126,6 +1129,10 @@ struct StepIO {
     float* lg_out; long long lg_stride;
     float* alpha_out;
     bool s1_from_prev = false;   // this step's LSTM1 sums are already in c.pre1 (computed over the parent rows)
+    // the selection of the PREVIOUS step, still to be made: it rides in this step's LSTM1 kernel (k_select_lstm1 / k_select_simple_lstm1;
+    // only with s1_from_prev).  sel_images: images of the beam selection (its parents are sel_beam->cb rows per image).
+    const SelBeamArgs* sel_beam = nullptr;
+    const SelSimpleArgs* sel_simple = nullptr;
     bool s1_for_next = false;    // compute the next step's LSTM1 sums together with this step's vocabulary GEMM
 };
 
@@ -1154,7 +1161,20 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
     uint16_t *s_t16 = sh ? c.s_t16 : nullptr, *g_t16 = sh ? c.g_t16 : nullptr, *att16 = sh ? c.att16 : nullptr;
 
     // ---- S1
-    if (io.s1_from_prev) {
+    if (io.s1_from_prev && io.sel_beam) {
+        const SelBeamArgs& sb = *io.sel_beam;
+        const int nslice = cdiv(H, SL_UB);
+#define SELL_LAUNCH(KK) hipLaunchKernelGGL((k_select_lstm1<KK>), dim3(sb.B * nslice), dim3((KK + 1) * 64), 0, s, sb, c.pre1, c.pre1_ns, c.pre1_stride, c.vproj, \
+                                           c1o, H, nslice, h1n, c1n, c.s_t, c.gpre, h->xproj, c.pre1_nblk, h1n16, s_t16, isc); break;
+        switch (sb.beam) {
+            case 1: SELL_LAUNCH(1) case 2: SELL_LAUNCH(2) case 3: SELL_LAUNCH(3) case 4: SELL_LAUNCH(4)
+            case 5: SELL_LAUNCH(5) case 6: SELL_LAUNCH(6) case 7: SELL_LAUNCH(7) default: SELL_LAUNCH(8)
+        }
+#undef SELL_LAUNCH
+    } else if (io.s1_from_prev && io.sel_simple) {
+        hipLaunchKernelGGL(k_select_simple_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, *io.sel_simple, c.pre1, c.pre1_ns, c.pre1_stride,
+                           c.vproj, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, c.pre1_nblk, h1n16, s_t16, isc);
+    } else if (io.s1_from_prev) {
         hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.pre1, c.pre1_ns, c.pre1_stride, c.vproj, io.rpi,
                            io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, c.pre1_nblk, 1, h1n16, s_t16, isc);
     } else {
@@ -1347,20 +1367,27 @@ static int decode_simple(vsr_handle* h, int vmode, uint64_t seed, const int64_t*
             hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(B, 256)), dim3(256), 0, s, forced_g + t, (long long)T, c.forced_g32 + (size_t)t * B, B, 2, c.nvalid_dev + 2);
         }
     }
+    // The selection of step t is per row and tiny: where the next step's LSTM1 kernel starts from cached sums (decode cache) it makes the
+    // selection itself (k_select_simple_lstm1) and k_select_simple is not launched for that step (VSR_FUSE_SELECT=0: always launched).
+    SelSimpleArgs pending{};
+    bool have_pending = false;
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
         StepIO io{};
         io.t = t; io.M = B; io.rpi = 1; io.cur = cur;
         io.parent = nullptr; io.word_prev = c.word[cur]; io.slot = c.slot[cur]; io.fixed_slot = 0;
+        io.sel_simple = have_pending ? &pending : nullptr;
         io.vmode = vmode; io.K = 1; io.full_out = nullptr; io.full_stride = 0;
         io.forced = (vmode == VM_FORCED) ? c.forced_w32 + (size_t)t * B : nullptr;
         io.seed = seed; io.verbs = verbs; io.gt = gt; io.lg_out = c.lg; io.lg_stride = 2; io.alpha_out = nullptr;
         io.s1_from_prev = t > 0 && h->xproj != nullptr;
         io.s1_for_next = t + 1 < T && h->xproj != nullptr;
         if (run_step(h, io, s)) return 1;
-        hipLaunchKernelGGL(k_select_simple, dim3(cdiv(B, 256)), dim3(256), 0, s, vmode, c.top_v, c.top_i, c.lg,
-                           (vmode == VM_FORCED) ? c.forced_g32 + (size_t)t * B : nullptr, seed, (uint32_t)t, c.slot[cur], c.L, B, T,
-                           c.word[cur ^ 1], c.gate[cur ^ 1], c.slot[cur ^ 1], words, gates, lp_w, lp_g);
+        const SelSimpleArgs sa{vmode, c.top_v, c.top_i, c.lg, (vmode == VM_FORCED) ? c.forced_g32 + (size_t)t * B : nullptr, seed, (uint32_t)t,
+                               c.slot[cur], c.L, B, T, c.word[cur ^ 1], c.gate[cur ^ 1], c.slot[cur ^ 1], words, gates, lp_w, lp_g};
+        have_pending = (h->fuse_select & 1) && t + 1 < T && h->xproj != nullptr;       // (the next step is then s1_from_prev)
+        if (have_pending) pending = sa;
+        else hipLaunchKernelGGL(k_select_simple, dim3(cdiv(B, 256)), dim3(256), 0, s, sa);
         LAUNCHCHK();
     }
     return 0;
@@ -1393,11 +1420,16 @@ extern "C" int vsr_beam(vsr_handle* h, int32_t beam, int32_t out_size, int64_t e
     const int B = c.B, T = h->d.seq_len;
     const int K = beam;
     if (zero_state(h, B, s)) return 1;
+    // The beam selection of step t rides in the LSTM1 kernel of step t + 1 (k_select_lstm1) wherever that kernel starts from cached sums
+    // (decode cache); the last step's, and every step's with VSR_FUSE_SELECT=0, is a launch of its own (k_select_beam).
+    SelBeamArgs pending{};
+    bool have_pending = false;
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
         const int cb = t == 0 ? 1 : beam;
         const int M = B * cb;
         StepIO io{};
+        io.sel_beam = have_pending ? &pending : nullptr;
         io.t = t; io.M = M; io.rpi = cb; io.cur = cur;
         io.parent = t == 0 ? nullptr : c.parent; io.word_prev = c.word[cur]; io.slot = c.slot[cur]; io.fixed_slot = 0;
         io.vmode = VM_TOPK; io.K = K; io.forced = nullptr; io.seed = 0; io.verbs = verbs; io.gt = gt;
@@ -1405,20 +1437,21 @@ extern "C" int vsr_beam(vsr_handle* h, int32_t beam, int32_t out_size, int64_t e
         io.s1_from_prev = t > 0 && h->xproj != nullptr;
         io.s1_for_next = t + 1 < T && h->xproj != nullptr;
         if (run_step(h, io, s)) return 1;
-#define SEL_ARGS t, cb, beam, c.L, eos_word, eos_gate, c.top_v, c.top_i, c.lg, c.slot[cur], c.word[cur], c.gate[cur], c.seq[cur], \
-                 c.seq[cur ^ 1], c.mask[cur], c.mask[cur ^ 1], c.word[cur ^ 1], c.gate[cur ^ 1], c.slot[cur ^ 1], c.parent,       \
-                 c.hist_parent, c.hist_word, c.hist_gate, c.hist_lpw, c.hist_lpg, B
-        switch (K) {
-            case 1: hipLaunchKernelGGL((k_select_beam<1>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
-            case 2: hipLaunchKernelGGL((k_select_beam<2>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
-            case 3: hipLaunchKernelGGL((k_select_beam<3>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
-            case 4: hipLaunchKernelGGL((k_select_beam<4>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
-            case 5: hipLaunchKernelGGL((k_select_beam<5>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
-            case 6: hipLaunchKernelGGL((k_select_beam<6>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
-            case 7: hipLaunchKernelGGL((k_select_beam<7>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
-            default: hipLaunchKernelGGL((k_select_beam<8>), dim3(B), dim3(64), 0, s, SEL_ARGS); break;
+        const SelBeamArgs sa{t, cb, beam, c.L, eos_word, eos_gate, c.top_v, c.top_i, c.lg, c.slot[cur], c.word[cur], c.gate[cur], c.seq[cur],
+                             c.seq[cur ^ 1], c.mask[cur], c.mask[cur ^ 1], c.word[cur ^ 1], c.gate[cur ^ 1], c.slot[cur ^ 1], c.parent,
+                             c.hist_parent, c.hist_word, c.hist_gate, c.hist_lpw, c.hist_lpg, B};
+        have_pending = (h->fuse_select & 2) && t + 1 < T && h->xproj != nullptr;       // (the next step is then s1_from_prev)
+        if (have_pending) pending = sa;
+        else switch (K) {
+            case 1: hipLaunchKernelGGL((k_select_beam<1>), dim3(B), dim3(64), 0, s, sa); break;
+            case 2: hipLaunchKernelGGL((k_select_beam<2>), dim3(B), dim3(64), 0, s, sa); break;
+            case 3: hipLaunchKernelGGL((k_select_beam<3>), dim3(B), dim3(64), 0, s, sa); break;
+            case 4: hipLaunchKernelGGL((k_select_beam<4>), dim3(B), dim3(64), 0, s, sa); break;
+            case 5: hipLaunchKernelGGL((k_select_beam<5>), dim3(B), dim3(64), 0, s, sa); break;
+            case 6: hipLaunchKernelGGL((k_select_beam<6>), dim3(B), dim3(64), 0, s, sa); break;
+            case 7: hipLaunchKernelGGL((k_select_beam<7>), dim3(B), dim3(64), 0, s, sa); break;
+            default: hipLaunchKernelGGL((k_select_beam<8>), dim3(B), dim3(64), 0, s, sa); break;
         }
-#undef SEL_ARGS
         LAUNCHCHK();
     }
     hipLaunchKernelGGL(k_backtrack, dim3(B), dim3(64), (size_t)3 * T * beam * sizeof(int), s, T, B, beam, out_size, c.seq[T & 1], c.hist_parent, c.hist_word,
