@@ -765,10 +765,27 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
     extern __shared__ float lrow[];          // V floats when the launch passes dynamic LDS: the combined row is
     const bool use_lds = lds_row != 0;       // summed from the slabs ONCE and the later passes read it from LDS
     const int row = blockIdx.x;
-    // the gate logits of this row (independent of the vocabulary work; nothing reads them before the selection kernel)
-    if (gate.M > 0) gatelogit_block<NT>(gate, row, red);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = logits + (long long)row * V;
+    const int V4 = (V + 3) & ~3;
+    const bool vec = ((V & 3) == 0);
+    // Slab sums for VU float4 groups per thread are loaded together (every slab of every group in flight at once).
+    constexpr int VU = 5, KU = NT == 512 ? 2 : 4;      // 512 threads: <= 128 VGPRs so that two rows share a CU
+    auto load_parts = [&](int vb, float4 (&part)[VU][KU + 1]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int v0 = vb + 4 * NT * u;
+            const bool in = v0 < V4;
+            part[u][0] = in ? *reinterpret_cast<const float4*>(bias + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < KU; ++k)
+                part[u][k + 1] = (in && k < nsplit) ? *reinterpret_cast<const float4*>(src + k * stride + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // the gate logits of this row (independent of the vocabulary work; nothing reads them before the selection kernel).  (Round 5: requesting
+    // the row's first round of loads BEFORE this block - so that its two barriers run under their round trip - keeps 60 more registers
+    // live across it: 155 VGPRs instead of 125, one row per CU instead of two.  Not kept.)
+    if (gate.M > 0) gatelogit_block<NT>(gate, row, red);
 
     // ---- verb forcing: thread 0 resolves the forced word, everybody takes the short path
     int verb = -1;
@@ -820,23 +837,11 @@ __global__ __launch_bounds__(NT) void k_vocab(const float* __restrict__ logits, 
     float bkey = -INFINITY;
     int bidx = 0x7fffffff;
     float mx = -INFINITY;
-    const int V4 = (V + 3) & ~3;
-    const bool vec = ((V & 3) == 0);
-    // Slab sums for VU float4 groups per thread are loaded together (every slab of every group in flight at once).
-    constexpr int VU = 5, KU = NT == 512 ? 2 : 4;      // 512 threads: <= 128 VGPRs so that two rows share a CU
     for (int vb = tid * 4; vb < V4; vb += 4 * NT * VU) {
         float xs_all[VU][4];
         if (vec) {
             float4 part[VU][KU + 1];
-#pragma unroll
-            for (int u = 0; u < VU; ++u) {
-                const int v0 = vb + 4 * NT * u;
-                const bool in = v0 < V4;
-                part[u][0] = in ? *reinterpret_cast<const float4*>(bias + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int k = 0; k < KU; ++k)
-                    part[u][k + 1] = (in && k < nsplit) ? *reinterpret_cast<const float4*>(src + k * stride + v0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            load_parts(vb, part);
 #pragma unroll
             for (int u = 0; u < VU; ++u) {
                 const int v0 = vb + 4 * NT * u;
@@ -1259,33 +1264,41 @@ __global__ __launch_bounds__((K + 1) * 64) void k_select_lstm1(const SelBeamArgs
                                                                float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t,
                                                                float* __restrict__ gpre, const float* __restrict__ xproj, int nblk,
                                                                uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16, float isc) {
-    __shared__ float sums[K * 6 * SL_UB];
+    __shared__ float sums[K * 7 * SL_UB];                  // per parent: six gate sums and its old cell state
     __shared__ int sel_s[2 * KMAX];
     const int b = blockIdx.x / nslice, slice = blockIdx.x % nslice;
     const int wave = threadIdx.x >> 6, u = threadIdx.x & 63, cb = sel.cb;
     const int j = slice * SL_UB + u;
+    float vp[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (wave == K) {
         select_beam_wave<K>(sel, b, u, slice == 0, sel_s);
-    } else if (wave < cb && j < H) {
-        const long long base = (long long)(b * cb + wave) * 6 * H + j;
+    } else if (j < H) {
+        // everything that does not depend on the selection is requested before the barrier: the parents' sums and cell states (into LDS:
+        // a child reads its parent's), the image's hoisted terms (the same for every row of the image)
 #pragma unroll
-        for (int g = 0; g < 6; ++g)
-            sums[(wave * 6 + g) * SL_UB + u] = g < nblk ? slab_sum(pre + base + (long long)g * H, nsplit, stride) : 0.f;
+        for (int g = 0; g < 6; ++g) vp[g] = vproj[(long long)b * 6 * H + (long long)g * H + j];
+        if (wave < cb) {
+            const long long base = (long long)(b * cb + wave) * 6 * H + j;
+            const float co = c1_old[(long long)(b * cb + wave) * H + j];
+#pragma unroll
+            for (int g = 0; g < 6; ++g)
+                sums[(wave * 7 + g) * SL_UB + u] = g < nblk ? slab_sum(pre + base + (long long)g * H, nsplit, stride) : 0.f;
+            sums[(wave * 7 + 6) * SL_UB + u] = co;
+        }
     }
     __syncthreads();
     if (wave == K || j >= H) return;
     const int pl = sel_s[wave], w = sel_s[KMAX + wave];
-    const int row = b * K + wave, prow = b * cb + pl;
-    const float* vp = vproj + (long long)b * 6 * H + j;
+    const int row = b * K + wave;
     const float* xp = xproj + (long long)w * 6 * H + j;
     float q[6];
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
-        float s = sums[(pl * 6 + g) * SL_UB + u];
+        float s = sums[(pl * 7 + g) * SL_UB + u];
         s += xp[(long long)g * H];
-        q[g] = s + vp[(long long)g * H];
+        q[g] = s + vp[g];
     }
-    lstm1_point(q, c1_old[(long long)prow * H + j], (long long)row * H + j, h1n, c1n, s_t, gpre, h1n16, s_t16, isc);
+    lstm1_point(q, sums[(pl * 7 + 6) * SL_UB + u], (long long)row * H + j, h1n, c1n, s_t, gpre, h1n16, s_t16, isc);
 }
 
 // final ordering by sequence log-prob + back-tracking through the parent pointers      (:182-194)

@@ -324,6 +324,8 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
             g.a.p[2].C = c2b; g.a.p[3].C = c2b + D;
             g.a.p[2].slab_stride = g.a.p[3].slab_stride = stride_b;
             if (g.launch(s, h)) return fail("train S2 gemm launch failed");
+            // (Round 5: k_gate2's work inside the attention kernel's row blocks, as in decoding, with the sentinel / s_a / the shift gate stored
+            // on the way for the backward pass: measured at no gain - 10.99-11.06 k against 10.85-11.10 k samples/s, profiles/r05_h_* - and not kept.)
             const long long n = (long long)B * (H + A + D + A);
             hipLaunchKernelGGL(k_gate2, dim3(cdiv(n, 256)), dim3(256), 0, s, c.scratch, c2b, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias,
                                B, H, A, D, g_t, hA, sent, sa, g1, g_t16, isc);
