@@ -71,6 +71,21 @@ def test_xe_gradient_norms_vs_reference(name):
     np.testing.assert_allclose(gn, g["grad_norm"], rtol=2e-3, atol=1e-8)
 
 
+@pytest.mark.parametrize("T", [62, 63, 70])
+def test_xe_gradients_long_sequences_across_the_dynamic_bound_table_limit(T):
+    """The f16x2 backward pass keeps the measured bounds of its gradient operands in 8 slots per timestep of a 512-slot table: up to
+    T = 62 it runs on the f16x2 kernels, from T = 63 on the f32x3 kernels (the forward pass stays f16x2; include/vsrcap.h,
+    vsr_refresh_h2_weights).  Both sides of the limit against the oracle's autograd, element by element (round-4 advisor finding 4)."""
+    cfg = dict(V=50, B=3, R0=6, R=6, D=64, L=T, T=T, E=64, H=64, A=32)
+    w = helpers.weights_for(cfg, gains={k: 1.0 for k in synth.DEFAULT_GAINS})
+    det, ctrl_seq, caps, gts = helpers.train_inputs(cfg, 23)
+    m = helpers.build_model(cfg, w, DEV)
+    loss, got = _device_grads(m, det, caps, ctrl_seq, gts)
+    ref_loss, want = _oracle_grads(w, cfg, det, caps, ctrl_seq, gts)
+    assert abs(loss - ref_loss) < 1e-4
+    _check(got, want, 2e-3)
+
+
 @pytest.mark.parametrize("flags", [dict(h2_first_lstm=False), dict(img_second_lstm=True)])
 def test_xe_gradients_config_flags(flags):
     cfg = dict(V=61, B=5, R0=6, R=7, D=128, L=4, T=7, E=32, H=48, A=16)

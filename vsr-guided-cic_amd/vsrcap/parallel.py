@@ -103,7 +103,7 @@ class DataParallelStep:
             raise ValueError("exchange_dtype must be torch.float32 or torch.bfloat16")
         self.exchange_dtype = exchange_dtype
         self._wire = None                  # bf16 image of the flat gradient buffer (exchange_dtype = bf16, caller-supplied SUM)
-        self._wires = {}                   # per bucket size: (send, recv, out) bf16 staging of the all-to-all exchange
+        self._wires = {}                   # shared bf16 staging (send, recv, out) + fp32 shard of the all-to-all exchange, sized for the largest bucket
         if self.model is not None:
             from . import _lib
             sd = dict(self.model.named_parameters())
@@ -165,16 +165,27 @@ class DataParallelStep:
         # once, and the shards are all-gathered.  Same bytes per link as a ring all-reduce of the bf16 image (2 (N-1)/N x 142 MB),
         # but an element is rounded TWICE whatever the world size - a ring that sums in bf16 rounds it up to N times
         # (tests/test_parallel.py states the deviation at world 2 and 8).
+        # Staging: ONE send / recv / out triple of bf16 and one fp32 shard, sized for the largest bucket and shared by all of them (the
+        # buckets are exchanged one after the other on this stream): 1.5 x the largest bucket in bf16 + its shard in fp32 of resident
+        # memory instead of a triple per bucket size, and no temporaries per call.
         world = self._world()
         n = buf.numel()
         shard = (n + world - 1) // world
-        key = (n, world, buf.device)
-        if key not in self._wires:
-            self._wires[key] = tuple(torch.zeros(world * shard, dtype=torch.bfloat16, device=buf.device) for _ in range(3))
-        send, recv, out = self._wires[key]
-        send[:n].copy_(buf)                                     # round to nearest even (the padding stays zero)
+        cap = max(world * ((g.bucket(b).numel() + world - 1) // world) for b in range(len(g.ranges)))
+        key = (cap, world, buf.device)
+        if self._wires.get("key") != key:
+            self._wires = {"key": key,
+                           "bf16": tuple(torch.zeros(cap, dtype=torch.bfloat16, device=buf.device) for _ in range(3)),
+                           "f32": torch.zeros(cap // world, dtype=torch.float32, device=buf.device)}
+        send, recv, out = (t[:world * shard] for t in self._wires["bf16"])
+        red32 = self._wires["f32"][:shard]
+        send[:n].copy_(buf)                                     # round to nearest even
+        if world * shard > n:
+            send[n:].zero_()                                    # (the padding of THIS bucket; the buffers are shared)
         dist.all_to_all_single(recv, send, group=self.group)    # stream-ordered on this (side) stream
-        red = recv.view(world, shard).float().sum(0).to(torch.bfloat16)
+        torch.sum(recv.view(world, shard), 0, dtype=torch.float32, out=red32)      # fp32 sum in rank order of the bf16 contributions
+        red = send[:shard]                                      # (send is free again: the all-to-all is stream-ordered)
+        red.copy_(red32)                                        # one rounding of the sum
         dist.all_gather_into_tensor(out, red, group=self.group)
         buf.copy_(out[:n])
         return None
