@@ -121,8 +121,6 @@ struct vsr_handle {
     // the selection of step t inside the LSTM1 kernel of step t + 1 (kernels.h: k_select_lstm1, k_select_simple_lstm1); VSR_FUSE_SELECT=0: a launch of its own
     int fuse_select = 3;              // bit 0: greedy / sampling / replay (k_select_simple_lstm1), bit 1: beam search (k_select_lstm1)
     bool b16_dma = true;              // bf16 mode: launches whose A operands all have bf16 images take the all-DMA kernel (VSR_B16_DMA=0: register-staged)
-    int h2a_skinny_nw = 3;            // DMA ring stages of the 128 x 128 tile of the all-DMA kernel (VSR_H2A_NW=3|4).  A fourth stage changes nothing (profiles/r05_e_*: 72.6 vs 73.8 us over the
-                                      // step GEMMs at M = 100, greedy 703-709 k vs 699 k tokens/s): its k loop is MFMA-bound (24 MFMAs per SIMD and 32-k tile = 0.5 us at the clock it holds), the rest of a 23 us launch is fixed cost
     int h2a_max_small = 128;          // launches of at most this many rows (and more than h2s_max) : 128 x 128 tiles of the all-DMA kernel
     std::vector<H2Range> h2t;         // the training pass's transposed operands (vsr_train_forward registers the images of its workspace)
     const H2Range* map_h2(const float* p, bool with_train = true) const {
@@ -520,8 +518,7 @@ int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     } else if (big == 38 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_b16a_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 38) hipLaunchKernelGGL((gemm_nt_b16a_kernel<2, 1>), grid, block, 0, s, a);
     else if (big == 37 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 2>), grid, block, 0, s, a);
-    else if (big == 37 && h->h2a_skinny_nw == 4) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1, 4>), grid, block, 0, s, a);
-    else if (big == 37) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1, 3>), grid, block, 0, s, a);
+    else if (big == 37) hipLaunchKernelGGL((gemm_nt_h2a_kernel<2, 1>), grid, block, 0, s, a);       // (a ring of four stages fits this tile and changes nothing: tools/gemm_bench H2_NW=4, profiles/r05_e_*)
     else if (big == 35 && x3_tn == 2) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 2>), grid, block, 0, s, a);
     else if (big == 35) hipLaunchKernelGGL((gemm_nt_h2_kernel<2, 1>), grid, block, 0, s, a);
     else if (big == 34) {
@@ -604,7 +601,6 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2_AIMG")) h->h2_aimg = atoi(e) != 0;
     if (const char* e = getenv("VSR_FUSE_SELECT")) h->fuse_select = atoi(e);
-    if (const char* e = getenv("VSR_H2A_NW")) h->h2a_skinny_nw = atoi(e) == 4 ? 4 : 3;
     if (const char* e = getenv("VSR_B16_DMA")) h->b16_dma = atoi(e) != 0;
     if (const char* e = getenv("VSR_ALIGNED_EFF")) h->aligned_eff_min = atoi(e) / 100.0;
     if (const char* e = getenv("VSR_X3S_SLOTS")) h->x3s_slots = std::max(1, atoi(e));
