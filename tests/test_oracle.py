@@ -167,6 +167,38 @@ def test_scst_500_fixture_slice_and_fresh_seed_subset():
     np.testing.assert_array_equal(bg.numpy(), g["beam_gates_%d" % seed][:6])
 
 
+def test_round5_fixtures_slices():
+    """g13_flip1024 (1 024 fresh captions: reference fp32 AND fp64-oracle ids) and g12_real_shapes (R0 = 100, R = 20; 16 images x 5
+    caption rows): the oracle reproduces the stored ids on small slices (the whole sets are decoded on the GPU box)."""
+    meta, g = load_golden("g13_flip1024")
+    cfg, seed = meta["cfg"], meta["seeds"][3]
+    lo = 3 * cfg["B"]
+    o, w = _oracle(meta)
+    det, ctrl = helpers.decode_inputs(cfg, seed, n=4)
+    with torch.no_grad():
+        gw, gg = o.test(det, ctrl)
+        (bw, bg), _ = o.beam_search(det, ctrl, meta["eos"], 5, 1)
+    np.testing.assert_array_equal(gw.numpy(), g["greedy_words"][lo:lo + 4])
+    np.testing.assert_array_equal(gg.numpy(), g["greedy_gates"][lo:lo + 4])
+    np.testing.assert_array_equal(bw.numpy(), g["beam_words"][lo:lo + 4])
+    np.testing.assert_array_equal(bg.numpy(), g["beam_gates"][lo:lo + 4])
+    # the reference's own count of captions that differ from the fp64 ids on this set: 0 and 0 (the bar the default GEMM flavour is held to)
+    assert (g["greedy_words"] == g["greedy_words64"]).all() and (g["beam_words"] == g["beam_words64"]).all()
+    assert (g["greedy_gates"] == g["greedy_gates64"]).all() and (g["beam_gates"] == g["beam_gates64"]).all()
+    assert len(np.unique(g["greedy_words"])) >= 1000 and 0.2 <= g["greedy_gates"].mean() <= 0.8
+
+    meta, g = load_golden("g12_real_shapes")
+    ce, n_caps = meta["cfg_eval"], meta["n_caps"]
+    o = vo.Oracle(w, ce["T"], meta["bos"], as_written=False)          # (same closed-form weights: default gains, seed 0)
+    det = torch.from_numpy(synth.make_detections(meta["n_img"], ce["R0"], ce["D"], seed=meta["seed_eval"]))
+    seqs = torch.from_numpy(synth.make_ctrl(meta["n_img"] * n_caps, ce["L"], ce["R"], ce["D"], seed=meta["seed_eval"]))
+    with torch.no_grad():
+        (bw, bg), _ = o.beam_search(det[:2].repeat_interleave(n_caps, 0), seqs[:2 * n_caps], meta["eos"], 5, 1)
+    np.testing.assert_array_equal(bw.numpy(), g["eval_words_noverb"][:2 * n_caps])
+    np.testing.assert_array_equal(bg.numpy(), g["eval_gates_noverb"][:2 * n_caps])
+    assert g["eval_noverb_agree64"].all() and g["xe_losses"][0] > 0
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference not mounted (GPU box)")
 def test_live_against_reference(tmp_path, monkeypatch):
     import json
