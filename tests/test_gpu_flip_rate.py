@@ -7,7 +7,8 @@ gate ids differs from the fp64 ids.  No fp32 implementation can be asked for few
 the headline default (f16x2) is: flips <= the reference's count - or it stops being the default.  The other two flavours are REPORTED and
 bounded at 2 per 1 024 (observed on the box, round 5: reference 0 / 0, f16x2 0 / 0, f32x3 0 / 1, f32 - the exact fp32 fma chain - 0 / 1,
 both on row 759 of the beam set: a row on which the fp32 reference and the fp64 oracle agree can still be within one fp32 rounding of a
-different beam, which is what "solid" in the 256-caption fixtures cannot promise either).
+different beam, which is what "solid" in the 256-caption fixtures cannot promise either; the unmodified reference itself flips row 759
+when it runs with ONE CPU thread instead of 2 / 4 / 8: tests/probes/reference_thread_stability.py).
 The counts and the flipped rows are printed (pytest -s / the -rA summary) and recorded in DESIGN.md section 2."""
 import numpy as np
 import pytest

@@ -81,3 +81,26 @@ def test_verb_forced_selection_inside_lstm1_is_bit_identical():
             (aw, ag), _ = mf.beam_search_v((det, ctrl, verbs), meta["eos"], 5, 1, gt=gt)
             (bw, bg), _ = ms.beam_search_v((det, ctrl, verbs), meta["eos"], 5, 1, gt=gt)
             _same(aw, bw, "verb-forced beam words gt=%s" % gt); _same(ag, bg, "verb-forced beam gates")
+
+
+@pytest.mark.parametrize("H", [72, 136])
+def test_selection_inside_lstm1_small_odd_sizes_vs_oracle(H):
+    """hidden sizes that are not multiples of the fused kernel's 64-unit slices (72 = one full + one 8-unit slice, 136 = 2 + 8), B = 3,
+    every beam width: fused == separate bit for bit, and the ids are the CPU oracle's."""
+    import vsr_oracle as vo
+    cfg = dict(V=50, B=3, R0=7, R=5, D=64, L=4, T=9, E=64, H=H, A=32)
+    w = helpers.weights_for(cfg)
+    mf, ms = _pair(cfg, w, 2)
+    det, ctrl = helpers.decode_inputs(cfg, 77)
+    o = vo.Oracle(w, cfg["T"], 2, as_written=False)
+    with torch.no_grad():
+        a, b = mf.test(det.to(DEV), ctrl.to(DEV)), ms.test(det.to(DEV), ctrl.to(DEV))
+        ow, og = o.test(det, ctrl)
+        _same(a[0], b[0], "greedy words"); _same(a[1], b[1], "greedy gates")
+        assert torch.equal(a[0].cpu(), ow) and torch.equal(a[1].cpu(), og)
+        for beam in (2, 4, 6, 7):
+            (aw, ag), (alw, alg) = mf.beam_search((det.to(DEV), ctrl.to(DEV)), [3, -1], beam, 2)
+            (bw, bg), (blw, blg) = ms.beam_search((det.to(DEV), ctrl.to(DEV)), [3, -1], beam, 2)
+            _same(aw, bw, "beam-%d words" % beam); _same(ag, bg, "beam-%d gates" % beam); _same(alw, blw, "beam-%d log-probs" % beam)
+            (obw, obg), _ = o.beam_search(det, ctrl, [3, -1], beam, 2)
+            assert torch.equal(aw.cpu()[:, 0], obw[:, 0]) and torch.equal(ag.cpu()[:, 0], obg[:, 0]), beam      # (the top hypothesis is well defined)
