@@ -8,6 +8,9 @@ untouched, so results are the shipped kernel's (gemm_bench checks them against f
   3  A requests first, then W (shipped: W first)
   4  movers at lower priority than the multipliers (s_setprio 0 / 3)
   5  the flush of round 4: band by band through one W stage also on k-aligned plans (shipped since round 5: the whole tile staged at once)
+  6  ABLATION (wrong sums, timings only; run with GEMM_NOCHECK=1): the multipliers read 12 instead of 16 operand fragments per k-tile (the lo planes of
+     the second k-half are not re-read): what would 25 % less LDS fragment traffic - a 64 x 128 wave tile - buy?
+  7  ABLATION: 8 instead of 16 fragment reads (no reads at all in the second k-half)
 usage: tools/h2a_variants.py ; then tools/gemm_bench_var<n> 500 256 4 5400 1"""
 import os, shutil, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -52,8 +55,36 @@ rep("        __syncthreads();                                   // k-tile 0 is r
     "        __syncthreads();                                   // k-tile 0 is ready\n        spread = true;\n        if constexpr (var == 4) __builtin_amdgcn_s_setprio(0);\n        // k-tile j: issue k-tile j + NW - 1")
 rep("        zero_acc();\n        bool first = true;\n", "        zero_acc();\n        bool first = true;\n        if constexpr (var == 4) __builtin_amdgcn_s_setprio(3);\n")
 rep("        if (args.aligned) {\n            // k-aligned plan: this piece is the workgroup's only one", "        if (args.aligned && var != 5) {\n            // k-aligned plan: this piece is the workgroup's only one")
+rep("""                f16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8_t*>(a_row + i * 32 * 64 + wh);
+                    al[i] = *reinterpret_cast<const f16x8_t*>(a_row + i * 32 * 64 + wl);
+                }
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    bh[jj] = *reinterpret_cast<const f16x8_t*>(b_row + jj * 32 * 64 + wh);
+                    bl[jj] = *reinterpret_cast<const f16x8_t*>(b_row + jj * 32 * 64 + wl);
+                }
+""", """#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (!(var == 7 && kk == 1)) ah[i] = *reinterpret_cast<const f16x8_t*>(a_row + i * 32 * 64 + wh);
+                    if (!((var == 6 || var == 7) && kk == 1)) al[i] = *reinterpret_cast<const f16x8_t*>(a_row + i * 32 * 64 + wl);
+                }
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    if (!(var == 7 && kk == 1)) bh[jj] = *reinterpret_cast<const f16x8_t*>(b_row + jj * 32 * 64 + wh);
+                    if (!((var == 6 || var == 7) && kk == 1)) bl[jj] = *reinterpret_cast<const f16x8_t*>(b_row + jj * 32 * 64 + wl);
+                }
+""")
+rep("""#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int wh = 8 * ((2 * kk + hh) ^ wsw)""", """            f16x8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int wh = 8 * ((2 * kk + hh) ^ wsw)""")
 open(p, "w").write(s)
 b = d + "/tools/gemm_bench.hip"
-procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-DH2A_VAR=%d" % n, "-o", ROOT + "/tools/gemm_bench_var%d" % n, b]) for n in (0, 1, 2, 3, 4, 5)]
+procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-DH2A_VAR=%d" % n, "-o", ROOT + "/tools/gemm_bench_var%d" % n, b]) for n in (0, 6, 7)]
 assert all(p.wait() == 0 for p in procs)
-print("built tools/gemm_bench_var0..5")
+print("built tools/gemm_bench_var0, 6, 7 (edit the tuple for the others)")
