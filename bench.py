@@ -271,7 +271,9 @@ def roofline_block(dtype, gemm_ms, gemm_n, gemm_seen, gemm_flops, dt, traffic=No
         if dtype == "f16x2":
             # the peak above is quoted at 2.4 GHz; under this load the chip holds ~1.5 GHz (profiles/r04_s_h2a_ablations.txt: the kernel with no
             # global traffic in its k loop reaches 85 % of the MFMA rate AT THAT CLOCK), so `frac` tops out near 0.6 here
-            r["sustained_clock_note"] = "peak quoted at 2.4 GHz; ~1.5 GHz sustained under this load (profiles/r04_s_h2a_ablations.txt)"
+            r["sustained_clock_note"] = ("peak quoted at 2.4 GHz; the chip holds ~1.74 GHz in these launches (power limit: 1.90 GHz without the weight DMAs, 2.14 GHz with idle "
+                                         "matrix pipes; profiles/r05_k_h2a_phase_stamps_and_fragment_read_ablation.txt part 3): 604 TFLOP/s fp32-equivalent at that clock")
+            r["frac_of_peak_at_sustained_clock"] = achieved / (PEAK_BF16_MFMA_TFLOPS / nmfma * 1.74 / 2.4)
             # the same launches against the HBM roofline (algorithmic bytes: every operand and output element once)
             gbs = gemm_bytes / (gemm_ms * 1e-3) / 1e9 if gemm_ms > 0 else 0.0
             r["hbm_view"] = {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
