@@ -136,7 +136,7 @@ int vsr_set_gemm_mode(vsr_handle* h, int32_t mode);
  * accumulation's, not the split's.  Call it again after every weight update (the images are not views); buffer = NULL: back to
  * mode 1 everywhere.  Sizes must be multiples of 8.  Turning it on or off voids what a change of mode voids.
  * Limits: (1) a state handed to vsr_step by the caller is taken as unit-bounded (|h| < 1, what sigmoid x tanh produces; scale 2^15):
- * larger values overflow fp16 - the f32x3 / f32 flavours accept any state.  (2) The backward pass keeps the measured bounds of its
+ * values of |h| >= 2 overflow fp16 - they are counted into vsr_bad_ids()'s count; the f32x3 / f32 flavours accept any state.  (2) The backward pass keeps the measured bounds of its
  * gradient operands in 8 slots per timestep of a 512-slot device table: up to T = 62 timesteps it runs on the f16x2 kernels, from
  * T = 63 on the f32x3 kernels (the forward pass stays f16x2; tests/test_gpu_train.py covers both sides of the limit).  (3) The
  * transposed operands of an f16x2 backward pass exist ONLY as images: a launch that names one and cannot take an f16x2 kernel

@@ -193,3 +193,29 @@ def test_h2_gemm_accuracy_with_loosened_bounds():
         rms[loose] = float(acc[1][2])
     print("rms error vs fp64 at K = 1000: fma chain %.3e, f16x2 %.3e, f16x2 with bounds loosened by 12 bits %.3e" % (rms["chain"], rms["0"], rms["12"]))
     assert rms["0"] <= 1.2 * rms["chain"] and rms["12"] <= 1.2 * rms["chain"]
+
+
+def test_h2_step_reports_states_outside_the_unit_class():
+    """vsr_step in the f16x2 flavour takes the caller's hidden states as unit-class operands (|h| < 2 at the fixed scale 2^15): a state
+    beyond that is counted by the input-contract check instead of silently overflowing fp16; a legal state reports nothing."""
+    import helpers
+    from conftest import load_golden
+    from vsrcap import synth
+    meta, _ = load_golden("g6_step")
+    cfg = meta["cfg"]
+    w = helpers.weights_for(cfg, wseed=meta.get("wseed", 0))
+    m = helpers.build_model(cfg, w, "cuda", bos=meta["bos"])
+    m.set_compute_dtype("f16x2")
+    det, ctrl = helpers.decode_inputs(cfg, meta["seed"])
+    B, H = cfg["B"], cfg["H"]
+    st = [torch.from_numpy((synth.hash_u01(B * H, 50 + i, 9).reshape(B, H) - 0.5).astype(np.float32)).cuda() for i in range(4)]
+    k0 = torch.tensor(meta["k0"], device="cuda")
+    prev = (torch.tensor(meta["prev_w"], device="cuda"), torch.tensor(meta["prev_g"], device="cuda"))
+    eng = m._engine(torch.device("cuda"))
+    eng.check_ids = True
+    with torch.no_grad():
+        m.step(meta["t"], ((st[0], st[1]), (st[2], st[3]), k0), prev, (det.cuda(), ctrl.cuda()), None, mode="feedback")     # fine
+        big = st[2].clone()
+        big[0, 0] = 3.0
+        with pytest.raises(IndexError):
+            m.step(meta["t"], ((st[0], st[1]), (big, st[3]), k0), prev, (det.cuda(), ctrl.cuda()), None, mode="feedback")

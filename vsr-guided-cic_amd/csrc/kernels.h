@@ -307,6 +307,16 @@ __global__ void k_init_rows(int* __restrict__ slot, int* __restrict__ word, int 
     if (i < n) { slot[i] = 0; word[i] = bos; }
 }
 
+// f16x2 flavour: a state handed to vsr_step by the caller is an A operand of class "unit" (|x| < 2 at the fixed scale 2^15: what
+// sigmoid x tanh produces); elements outside that range would overflow fp16 in the GEMMs' in-kernel split.  They are COUNTED into the
+// input-contract counter (vsr_bad_ids) - the f32x3 / f32 flavours accept any state.
+__global__ void k_count_outside_unit(const float* __restrict__ x, long long n, int* __restrict__ count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bad = i < n && !(fabsf(x[i]) < 1.9990234375f);          // (NaN counts too)
+    const unsigned long long b = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, __popcll(b));
+}
+
 __global__ void k_fill_i32(int* p, int v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

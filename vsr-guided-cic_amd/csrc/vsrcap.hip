@@ -1508,6 +1508,11 @@ extern "C" int vsr_step(vsr_handle* h, int32_t t, int32_t rows_per_image, const 
     float* out[4] = {h1_out, c1_out, h2_out, c2_out};
     for (int j = 0; j < 4; ++j) HIPCHK(hipMemcpyAsync(c.st[0][j], in[j], n, hipMemcpyDeviceToDevice, s));
     c.st16_ok[0] = false;                     // the caller's state has no bf16 image
+    if (h->h2_on && !h->bf16_on && h->x3_on) {           // f16x2: the hidden states are unit-class GEMM operands (include/vsrcap.h, limits of the flavour)
+        const long long ne = (long long)M * H;
+        hipLaunchKernelGGL(k_count_outside_unit, dim3(cdiv(ne, 256)), dim3(256), 0, s, h1, ne, c.nvalid_dev + 2);
+        hipLaunchKernelGGL(k_count_outside_unit, dim3(cdiv(ne, 256)), dim3(256), 0, s, h2, ne, c.nvalid_dev + 2);
+    }
     hipLaunchKernelGGL(k_step_slots, dim3(cdiv(M, 256)), dim3(256), 0, s, t, slot, prev_gates, c.L, M, c.slot[0], slot_out);
     if (t == 0) hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, c.word[0], h->d.bos_idx, M);
     else hipLaunchKernelGGL(k_i64_to_i32, dim3(cdiv(M, 256)), dim3(256), 0, s, prev_words, 1LL, c.word[0], M, V, c.nvalid_dev + 2);
