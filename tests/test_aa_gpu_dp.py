@@ -73,3 +73,40 @@ def test_two_ranks_two_gpus_rccl(tmp_path):
     one = _run(tmp_path, "nccl", 1, False, "one")
     two = _run(tmp_path, "nccl", 2, False, "two")
     _compare(one, two)
+
+
+def test_rccl_collectives_of_the_exchange_on_one_rank(tmp_path):
+    """The data-parallel exchange's RCCL calls on real hardware, as far as a 1-GPU box allows: a ONE-rank "nccl" (= RCCL) process group on
+    cuda:0, then the two wire formats of DataParallelStep._exchange_bucket on a plain parameter list - fp32 all-reduce, and the bf16 wire
+    (all-to-all of the bf16 image, fp32 sum, all-gather) through the shared staging buffers - bucket by bucket.  With one rank the sum
+    is the rank's own contribution: fp32 comes back bit-identical, bf16 comes back rounded to bf16 once (a second rounding of a bf16
+    value changes nothing).  (More than one rank: test_two_ranks_two_gpus_rccl, skipped below 2 GPUs.)"""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(%r, "vsr-guided-cic_amd"))
+from vsrcap import parallel
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = "%d"
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+params = [torch.nn.Parameter(torch.randn(n, device="cuda")) for n in (1000, 37, 4096, 513)]
+opt = torch.optim.SGD(params, lr=0.1)
+for dt in (torch.float32, torch.bfloat16):
+    st = parallel.DataParallelStep(params, opt, exchange_dtype=dt)
+    st.grads = parallel.FlatGrads(params, bucket_of=[0, 0, 1, 2])
+    g = st.grads
+    g.flat.copy_(torch.randn_like(g.flat) * 3.0)
+    want = g.flat.clone() if dt == torch.float32 else g.flat.to(torch.bfloat16).float()
+    for b in range(len(g.ranges)):
+        w = st._exchange_bucket(g.bucket(b))
+        if w is not None:
+            w.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(g.flat, want), (dt, (g.flat - want).abs().max().item())
+t = torch.ones(8, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
+assert float(t.sum()) == 8.0
+dist.destroy_process_group()
+print("rccl one-rank exchange ok")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), _port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl one-rank exchange ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
