@@ -25,6 +25,10 @@ Fixtures:
                                           eval_coco.py:55-57,240-247): XE step at B = 100 with R0 = 100 pooled detections, slots of
                                           R = 20 regions, L = T = 20; beam_search_v over 16 images x 5 caption rows (L = 10, R = 20,
                                           verbs, beam 5), called per image like the eval script does
+  g14_xe_traj / g14_xe_traj_small         the training LOOP of coco_scripts/train.py:92-120 on the reference: 5 XE steps with
+                                          Adam(lr=5e-4) (train.py:77), a different synthetic batch per step, at B = 100 full size (and
+                                          at config-1 size): loss / loss_cap / loss_gate per step, norms of the 28 parameters' total
+                                          change - "training trains", per step, whatever optimizer flavour moves the weights
   g13_flip1024                            16 FRESH seeds x 64 images (no margin search): greedy + beam-5 ids of the reference (fp32)
                                           AND of the fp64 oracle, greedy margins, beam score gaps - the flip-rate fixture
 """
@@ -128,8 +132,8 @@ def pick_seed_and_greedy(c):
 
 def main():
     """Stages are independent and resumable:
-    python tests/golden/make_golden.py [small] [greedy] [beam] [verbs] [sample] [stepv] [xe100] [scst500] [fresh] [real] [flip1024]
-    (the last two only on request: they take ~1 h of CPU)"""
+    python tests/golden/make_golden.py [small] [greedy] [beam] [verbs] [sample] [stepv] [xe100] [scst500] [fresh] [real] [flip1024] [traj]
+    (real / flip1024 only on request: they take ~1 h of CPU; traj: ~3 min)"""
     stages = sys.argv[1:] or ["small", "greedy", "beam", "verbs", "sample", "stepv", "xe100", "scst500", "fresh"]
     torch.manual_seed(0)
     tmp = tempfile.mkdtemp()
@@ -152,6 +156,8 @@ def main():
         t0 = time.time()
         xe_fixture("g1_xe_b100", cfg_full(100), {k: 1.0 for k in synth.DEFAULT_GAINS}, seed=7)
         print("XE B=100 fixture %.1fs" % (time.time() - t0))
+    if "traj" in stages:
+        stage_traj()
     if "scst500" in stages:
         stage_scst500()
     if "fresh" in stages:
@@ -160,7 +166,7 @@ def main():
         stage_real()
     if "flip1024" in stages:
         stage_flip1024()
-    if not (set(stages) - {"small", "stepv", "xe100", "scst500", "fresh", "real", "flip1024"}):
+    if not (set(stages) - {"small", "stepv", "xe100", "scst500", "fresh", "real", "flip1024", "traj"}):
         return
     cF = cfg_full(256)
     if "greedy" in stages:
@@ -180,6 +186,46 @@ def main():
         stage_verbs(m, cF, meta, det, ctrl, seed, eos, tables)
     if "sample" in stages:
         stage_sample(m, meta, det, ctrl)
+
+
+def traj_fixture(name, c, gains, seed, steps=5, lr=5e-4, feat_scale=1.0):
+    """coco_scripts/train.py:92-120 re-enacted on the imported reference: model.train(); per batch: forward (:103), the two NLL losses
+    (:106-110), optim.zero_grad / loss.backward / optim.step (:111-113) with Adam(lr) (:77).  Batch i = synthetic batch of seed + i."""
+    m, w = build_ref(c, gains)
+    m.train()
+    w0 = {k: p.detach().clone() for k, p in m.named_parameters()}
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    losses = []
+    t0 = time.time()
+    for i in range(steps):
+        det, ctrl_seq = (x * feat_scale for x in inputs(c, seed + i, train=True))
+        caps = torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed + i))
+        gts = torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed + i))
+        out, gate = m((det,), (caps, ctrl_seq))
+        loss, lc, lg = vo.xe_loss(out, gate, caps, gts)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append([loss.item(), lc.item(), lg.item()])
+        print("%s step %d: loss %.6f (cap %.6f, gate %.6f)  %.1fs" % (name, i, loss.item(), lc.item(), lg.item(), time.time() - t0), flush=True)
+    dn = [float((p.detach() - w0[k]).double().norm()) for k, p in m.named_parameters()]
+    wn = [float(p.detach().double().norm()) for k, p in m.named_parameters()]
+    # a held-out evaluation of the trained weights: XE loss of batch seed + steps under no_grad (what "the final weights" means to a caller)
+    det, ctrl_seq = (x * feat_scale for x in inputs(c, seed + steps, train=True))
+    caps = torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed + steps))
+    gts = torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed + steps))
+    with torch.no_grad():
+        out, gate = m((det,), (caps, ctrl_seq))
+        held = [x.item() for x in vo.xe_loss(out, gate, caps, gts)]
+    save(name, dict(cfg=c, gains=gains, seed=seed, wseed=0, bos=BOS, steps=steps, lr=lr, optimizer="Adam", feat_scale=feat_scale, param_order=list(w.keys())),
+         losses=np.array(losses, dtype=np.float64), delta_norm=np.array(dn, dtype=np.float64), final_norm=np.array(wn, dtype=np.float64),
+         heldout_losses=np.array(held, dtype=np.float64))
+
+
+def stage_traj():
+    fs = float(os.environ.get("TRAJ_FEAT_SCALE", "0.0625"))
+    traj_fixture("g14_xe_traj_small", cfg_small(), {k: 1.0 for k in synth.DEFAULT_GAINS}, seed=40, feat_scale=fs)
+    traj_fixture("g14_xe_traj", cfg_full(100), {k: 1.0 for k in synth.DEFAULT_GAINS}, seed=40, feat_scale=fs)
 
 
 def stage_small(cS, cW, tables):

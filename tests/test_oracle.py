@@ -232,3 +232,24 @@ print("LIVE-OK")
     (tmp_path / "datasets" / "coco" / "verb_2_vob.json").write_text("{}")
     r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert "LIVE-OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_oracle_training_trajectory_small():
+    """g14_xe_traj_small: 5 Adam steps of the reference's training loop (coco_scripts/train.py:92-120) - the oracle under the same loop"""
+    import helpers
+    meta, g = load_golden("g14_xe_traj_small")
+    cfg, fs = meta["cfg"], meta["feat_scale"]
+    w = helpers.weights_for(cfg, gains=meta["gains"])
+    o = vo.Oracle(w, cfg["T"], meta["bos"], as_written=True)
+    params = [o.p[k].requires_grad_(True) for k in o.p]
+    opt = torch.optim.Adam(params, lr=meta["lr"])
+    losses = []
+    for i in range(meta["steps"]):
+        det, ctrl_seq, caps, gts = helpers.train_inputs(cfg, meta["seed"] + i)
+        out, gate = o.forward(det * fs, caps, ctrl_seq * fs)
+        loss, lc, lg = vo.xe_loss(out, gate, caps, gts)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append([loss.item(), lc.item(), lg.item()])
+    np.testing.assert_allclose(np.array(losses), g["losses"], atol=2e-5, rtol=0)

@@ -86,6 +86,7 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
             // k-aligned plan: this piece is the workgroup's only one, nothing is prefetched behind it, the whole ring is free: stage all 128
             // rows at once - two barriers instead of eight, every thread's stores back to back (the flush is 3 of a skinny launch's 23 us)
             static_assert(BM * ST_LD * 4 <= NW * STG * 2, "whole-tile staging must fit the ring");
+            static_assert(BM % RPP == 0, "the whole-tile flush walks BM / RPP row groups with no remainder handling");
             float* const all = reinterpret_cast<float*>(sW);
             if constexpr (decltype(MULT)::value) {
 #pragma unroll

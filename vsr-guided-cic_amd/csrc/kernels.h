@@ -265,6 +265,15 @@ __global__ void k_pad_row_list(int* __restrict__ vlist, int* __restrict__ counts
     if (i >= n && i < bound) vlist[i] = n > 0 ? vlist[0] : 0;
 }
 
+// rows vlist[bound .. n) of P = 0: the non-padding rows a caller's bound left without a projection (n = counts[0] on the device)
+__global__ void k_zero_rows_beyond(const int* __restrict__ vlist, const int* __restrict__ counts, int bound, int A, float* __restrict__ P) {
+    const int n = counts[0];
+    for (int i = bound + (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+        float* row = P + (long long)vlist[i] * A;
+        for (int a = threadIdx.x; a < A; a += blockDim.x) row[a] = 0.f;
+    }
+}
+
 // P[vlist[m]] = sum of the slabs' row m   (scatter of the compact projection back to the dense row index)
 // rows_dev (optional): the number of real rows lives on the device (the launch covers `rows` = the caller's bound)
 __global__ void k_slab_reduce_scatter(const float* __restrict__ slabs, int nslab, long long stride, int rows, int A,

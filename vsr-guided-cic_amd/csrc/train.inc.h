@@ -186,20 +186,20 @@ static void colsum(TrainCtx& t, hipStream_t s, const float* X, long long ld, int
 // buffer `out` then only lends its address
 // self_slot >= 0: `out` itself receives the image (an A operand: a transposed gradient, scaled by the bound in that slot of the table)
 static void transpose(vsr_handle* h, hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out,
-                      const int* list = nullptr, bool h2img = false, int self_slot = -1) {
+                      const int* list = nullptr, bool h2img = false, int self_slot = -1, const int* rlimit = nullptr) {
     uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(out)) : nullptr;
     const dim3 grid(cdiv(C, 64), cdiv(R, 64)), block(256);
     const H2Range* r2 = (h2img && !tw) ? h->map_h2(out) : nullptr;
     if (h2img && !tw && !r2 && self_slot >= 0 && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 31) == 0) {
         uint16_t* img = reinterpret_cast<uint16_t*>(out);
-        if (list) hipLaunchKernelGGL((k_transpose_t<true, 2>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, img, h->h2_exps, self_slot);
+        if (list) hipLaunchKernelGGL((k_transpose_t<true, 2>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, img, h->h2_exps, self_slot, rlimit);
         else hipLaunchKernelGGL((k_transpose_t<false, 2>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, img, h->h2_exps, self_slot);
     } else if (r2) {
         uint16_t* img = reinterpret_cast<uint16_t*>(const_cast<float*>(r2->img + (out - r2->lo)));
-        if (list) hipLaunchKernelGGL((k_transpose_t<true, 2>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, img, h->h2_exps, r2->slot);
+        if (list) hipLaunchKernelGGL((k_transpose_t<true, 2>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, img, h->h2_exps, r2->slot, rlimit);
         else hipLaunchKernelGGL((k_transpose_t<false, 2>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, img, h->h2_exps, r2->slot);
-    } else if (list && tw) hipLaunchKernelGGL((k_transpose_t<true, 1>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, tw);
-    else if (list) hipLaunchKernelGGL((k_transpose_t<true, 0>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, (uint16_t*)nullptr);
+    } else if (list && tw) hipLaunchKernelGGL((k_transpose_t<true, 1>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, tw, (const int*)nullptr, 0, rlimit);
+    else if (list) hipLaunchKernelGGL((k_transpose_t<true, 0>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, (uint16_t*)nullptr, (const int*)nullptr, 0, rlimit);
     else if (tw) hipLaunchKernelGGL((k_transpose_t<false, 1>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, tw);
     else hipLaunchKernelGGL((k_transpose_t<false, 0>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, (uint16_t*)nullptr);
 }
@@ -482,6 +482,9 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     HIPCHK(hipMemsetAsync(t.dc1_c[0], 0, BH * sizeof(float), s));
     HIPCHK(hipMemsetAsync(t.dc2_c[0], 0, BH * sizeof(float), s));
     const int NV = c.nvalid, NVp = (int)up4((size_t)NV);     // non-padding region rows: the only ones att_va saw
+    // under a caller's row bound (vsr_set_valid_rows_bound) NV is the BOUND and the list's tail [n, NV) repeats its first entry: the two
+    // gathers below read those rows as zeros (k_transpose_t's rlimit = the device-side count), so att_va's gradient sums over n rows
+    const int* nv_dev = c.bounded ? c.nvalid_dev : nullptr;
     // (the K padding of the transposed operands - TBp, Bp, NVp columns - is zero-filled by the transposing kernel itself)
 
     // ---- phase 0: dlogits (t,b) and the vocabulary part of dh2 for every step
@@ -609,7 +612,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     transpose(h, s, t.g_ts, H, TB, H, t.tX_gt, TBp, nullptr, h2b);
     transpose(h, s, h2cur, H, TB, H, t.tX_h2, TBp, nullptr, h2b);
     transpose(h, s, c.vbar, D, B, D, t.tX_vbar, Bp, nullptr, h2b);
-    if (NV > 0) transpose(h, s, c.regions, (long long)D, NV, D, t.tX_reg, (long long)NVp, c.vlist, h2b);
+    if (NV > 0) transpose(h, s, c.regions, (long long)D, NV, D, t.tX_reg, (long long)NVp, c.vlist, h2b, -1, nv_dev);
     if (h2b) hipLaunchKernelGGL(k_h2_dyn_fold, dim3(1), dim3(64), 0, s, dyn, T);
     const int sP1 = dslot(DW_step + DY_dpre1), sQ = dslot(DW_step + DY_dq), sP2 = dslot(DW_step + DY_dpre2);
     // the transposed gradients are the A operands of the weight-gradient GEMMs: with the whole-pass bounds known (k_h2_dyn_fold) they are
@@ -635,7 +638,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         hipLaunchKernelGGL(k_absmax, dim3((unsigned)std::min<long long>(1024, cdiv(ndp, 1024))), dim3(256), 0, s, dP_rows, ndp, reinterpret_cast<unsigned*>(dyn + DW_dP));
     }
     const bool tyiP = tyi && NVp % 8 == 0;
-    if (NV > 0) transpose(h, s, dP_rows, (long long)A, NV, A, t.tY_dP, (long long)NVp, c.vlist, tyiP, dslot(DW_dP));
+    if (NV > 0) transpose(h, s, dP_rows, (long long)A, NV, A, t.tY_dP, (long long)NVp, c.vlist, tyiP, dslot(DW_dP), nv_dev);
     hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 6 * H, 256)), dim3(256), 0, s, t.dpre1, T, (long long)B * 6 * H, t.dpre1sum);
     transpose(h, s, t.dpre1sum, 6 * H, B, 6 * H, t.tY_dpre1sum, Bp);
     LAUNCHCHK();

@@ -56,8 +56,11 @@ __device__ __forceinline__ void block_absmax_to(float m, int* bm) {
 template <bool GATHER, int IMG>
 __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int R, int C,
                                                      float* __restrict__ out, long long ld_out, uint16_t* __restrict__ out16,
-                                                     const int* __restrict__ exps = nullptr, int slot = 0) {
+                                                     const int* __restrict__ exps = nullptr, int slot = 0, const int* __restrict__ rlimit = nullptr) {
     constexpr bool BF16 = IMG != 0;            // (either image kind: the fp32 buffer is not written)
+    // rlimit (device): input rows from *rlimit up are taken as ZERO rows - the row list of a vsr_prepare*() under a caller's row bound is
+    // padded to the bound with copies of its first entry (k_pad_row_list), which the weight-gradient reduction must not see
+    const int Rl = rlimit ? min(R, *rlimit) : R;
     float isc = 0.f;
     if constexpr (IMG == 2) {                   // (slots from H2_DYN0 up hold the measured BOUND of a gradient operand, not its exponent: gemm_h2.h)
         const int ev = exps[slot];
@@ -72,7 +75,9 @@ __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + p + 16 * i, c = c0 + 4 * q;
-        if (r < R) {
+        if (r >= Rl && r < R) {
+            t[p + 16 * i][4 * q] = 0.f; t[p + 16 * i][4 * q + 1] = 0.f; t[p + 16 * i][4 * q + 2] = 0.f; t[p + 16 * i][4 * q + 3] = 0.f;
+        } else if (r < R) {
             const float* src = in + (long long)(GATHER ? list[r] : r) * ld_in;
             if (vin && c + 3 < C) {
                 const float4 v = *reinterpret_cast<const float4*>(src + c);

@@ -65,6 +65,7 @@ struct Ctx {
     int *vlist, *nvalid_dev;     // non-padding region rows (ascending) and their number
     int* bcount;                 // per-256-row counts / offsets of the compaction
     int nvalid = 0;
+    bool bounded = false;        // nvalid is the caller's row bound (vsr_set_valid_rows_bound), the real count lives in nvalid_dev[0]
     float* st[2][4];   // h1, c1, h2, c2 double-buffered
     int *slot[2], *word[2], *gate[2], *parent;
     float *s_t, *gpre, *g_t, *hA, *sa, *sent, *att, *zsum, *lg, *top_v;
@@ -1053,8 +1054,13 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
         hipLaunchKernelGGL(k_slab_reduce, dim3(cdiv(stride, 256)), dim3(256), 0, s, c.scratch, ns, stride, stride, c.vproj2);
         LAUNCHCHK();
     }
+    c.bounded = bound > 0;
     if (bound > 0) {
         c.nvalid = (int)bound;         // (bad slot indices of the index-list format join the bad-id count: vsr_bad_ids)
+        // a bound that is too small: the rows vlist[bound .. n) get no projection.  Their P rows are ZEROED (att_va = 0, a defined result)
+        // instead of keeping whatever the workspace held, and their number is in vsr_bad_ids()'s count
+        if (prows > bound)
+            hipLaunchKernelGGL(k_zero_rows_beyond, dim3((unsigned)std::min<long long>(prows - bound, 2048)), dim3(128), 0, s, c.vlist, c.nvalid_dev, (int)bound, A, c.P);
     } else {
         HIPCHK(hipEventSynchronize(h->ev_count));
         c.nvalid = back[0];

@@ -29,6 +29,35 @@ DEFAULT_COMPUTE_DTYPE = 'f16x2'
 COMPUTE_DTYPES = ('f32', 'f32x3', 'f16x2', 'bf16')
 
 
+# ---- the weights' GENERATION ------------------------------------------------------------------------------------------------
+# The reference reads its parameters live at every step (controllable_captioning.py:151-152,177-178; coco_scripts/train.py:112-113 steps
+# the optimizer and the next model(...) at :103 sees the new weights).  Here three things are DERIVED from the weights and have to be
+# redone when they move: the fp16-pair images (f16x2), the bf16 copies (bf16) and the decode cache (inference).  What says "they moved":
+#   (1) model._wgen, bumped by invalidate_cache(), train() / eval(), load_state_dict(), attach_optimizer()'s hook - and by EVERY forward
+#       that builds a graph (training: the weights are expected to move between two such calls, whoever moves them);
+#   (2) _OPT_STEPS, a process-wide count of torch.optim.Optimizer.step() calls (a global post-step hook): any optimizer stepping
+#       anywhere voids every model's derived state, so an evaluation between two steps never sees stale images;
+#   (3) sum(p._version) - in-place edits through torch ops.  NOT sufficient on its own: fused optimizers (Adam / SGD(fused=True))
+#       update the parameters in place and leave _version untouched on this torch build (round-5 review).
+# Writes none of these sees (p.data edits, DLPack / custom kernels into the same storage) in eval mode: call invalidate_cache().
+_OPT_STEPS = [0]
+_OPT_HOOK = []
+
+
+def _count_optimizer_steps():
+    if _OPT_HOOK:
+        return
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+    except ImportError:                  # (older torch: training forwards and attach_optimizer() still cover the training loop)
+        _OPT_HOOK.append(None)
+        return
+
+    def _after_step(opt, args, kwargs):
+        _OPT_STEPS[0] += 1
+    _OPT_HOOK.append(register_optimizer_step_post_hook(_after_step))
+
+
 def set_default_compute_dtype(dtype):
     """compute dtype of models constructed from now on ('f32' = exact fma chain everywhere, 'f32x3', 'f16x2', 'bf16'); returns the old one"""
     global DEFAULT_COMPUTE_DTYPE
@@ -85,7 +114,9 @@ class ControllableCaptioningModel(CaptioningModel):
         self.init_weights()
         self._eng = None
         self._verb_dev = None
-        # prepare() caches the hoisted per-image tensors keyed on (data_ptr, tensor._version, shapes, weights version);
+        self._wgen = 0                   # the weights' generation (module comment above)
+        _count_optimizer_steps()
+        # prepare() caches the hoisted per-image tensors keyed on (data_ptr, tensor._version, shapes, weights generation);
         # set force_prepare = True when inputs / weights are rewritten in ways that do not bump _version
         # (t.data.copy_, DLPack / custom-kernel writes, p.data edits), or call invalidate_cache() after such a write
         self.force_prepare = False
@@ -117,8 +148,29 @@ class ControllableCaptioningModel(CaptioningModel):
         return self
 
     def invalidate_cache(self):
+        """the weights (or inputs) were rewritten in a way nothing above can see: everything derived from them is redone by the next call"""
+        self._wgen += 1
         if self._eng is not None:
             self._eng.invalidate()
+
+    def attach_optimizer(self, optimizer):
+        """Extension: tie an optimizer's step() to this model's weight generation (a per-optimizer post-step hook).  torch optimizers are
+        already counted process-wide (_OPT_STEPS); this is for optimizer classes that do not run torch's step hooks.  Returns the hook
+        handle (or None when the object has no register_step_post_hook)."""
+        reg = getattr(optimizer, "register_step_post_hook", None)
+        if reg is None:
+            return None
+        return reg(lambda opt, args, kwargs: self.invalidate_cache())
+
+    def train(self, mode=True):
+        # a mode switch redoes the derived state: eval() after a training run must decode with the FINAL weights whatever moved them
+        if mode != self.training:
+            self._wgen = getattr(self, "_wgen", 0) + 1
+        return super().train(mode)
+
+    def load_state_dict(self, *a, **kw):
+        self._wgen = getattr(self, "_wgen", 0) + 1
+        return super().load_state_dict(*a, **kw)
 
     def init_weights(self):
         for name, p in self.named_parameters():
@@ -134,7 +186,10 @@ class ControllableCaptioningModel(CaptioningModel):
         return (z(), z()), (z(), z()), torch.zeros((b_s,), dtype=torch.long, device=device)
 
     # ------------------------------------------------------------------ engine plumbing
-    def _engine(self, device):
+    def _engine(self, device, weights_may_have_moved=False):
+        """weights_may_have_moved: the caller builds an autograd graph (a training forward): the derived weight state is redone"""
+        if weights_may_have_moved:
+            self._wgen += 1
         if device.type != 'cuda':
             raise RuntimeError("ControllableCaptioningModel (MI355X build) computes only on the GPU: move the model and "
                                "its inputs to 'cuda'. There is no CPU fallback.")
@@ -168,7 +223,10 @@ class ControllableCaptioningModel(CaptioningModel):
         return self._eng
 
     def _weights_version(self):
-        return sum(p._version for p in self.parameters())
+        return (self._wgen, _OPT_STEPS[0], sum(p._version for p in self.parameters()))
+
+    def _builds_graph(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     def _verbs(self, eng, verbs, device, rows=None, L=None):
         if rows is not None and tuple(verbs.shape) != (rows, L):
@@ -194,11 +252,12 @@ class ControllableCaptioningModel(CaptioningModel):
     # ------------------------------------------------------------------ loops (CaptioningModel hooks)
     def _run_forward(self, statics, seqs):
         det, (captions, ctrl_seq) = statics[0], seqs
-        eng = self._engine(det.device)
+        with_grad = self._builds_graph()
+        eng = self._engine(det.device, weights_may_have_moved=with_grad)
         if captions.size(1) > self.seq_len:
             raise RuntimeError("captions longer than seq_len")
         from vsrcap.regions import IndexedRegions
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if with_grad:
             if isinstance(ctrl_seq, IndexedRegions) and ctrl_seq.row_img is not None:
                 raise RuntimeError("training on IndexedRegions needs one decoder row per image (row_img=None), as the reference's "
                                    "training batches have; with a row -> image map train on regions.dense()")
@@ -222,9 +281,9 @@ class ControllableCaptioningModel(CaptioningModel):
 
     def _run_sample(self, statics, seed=None, forced=None):
         det, ctrl = statics[0], statics[1]
-        eng = self._engine(det.device)
+        with_grad = self._builds_graph()
+        eng = self._engine(det.device, weights_may_have_moved=with_grad)
         from vsrcap.regions import IndexedRegions
-        with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if with_grad and isinstance(ctrl, IndexedRegions) and ctrl.row_img is not None:
             raise RuntimeError("sample_rl with gradients on IndexedRegions needs one decoder row per image (row_img=None)")
         B = self._prepare(eng, det, ctrl, 1)
@@ -236,7 +295,7 @@ class ControllableCaptioningModel(CaptioningModel):
             if dist.is_available() and dist.is_initialized():
                 seed ^= (dist.get_rank() + 1) << 48
         outs, lps = eng.sample(B, det.device, seed, forced)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if with_grad:
             from vsrcap.train import sample_logprobs_with_grad
             lps = sample_logprobs_with_grad(self, eng, det, ctrl, outs, lps)
         return outs, lps

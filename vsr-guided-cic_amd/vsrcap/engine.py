@@ -36,6 +36,21 @@ def _f32(t, name):
     return t.contiguous()
 
 
+_UNVERSIONED = [0]
+
+
+def _ver(t):
+    """in-place-write counter of a tensor for the prepare() cache key.  Tensors created under torch.inference_mode() track none
+    (reading t._version raises): such an input gets a fresh key every time, i.e. it is never served from the cache."""
+    if t is None:
+        return None
+    try:
+        return t._version
+    except RuntimeError:
+        _UNVERSIONED[0] += 1
+        return ("unversioned", _UNVERSIONED[0])
+
+
 class _Null:
     def __enter__(self):
         return self
@@ -93,7 +108,7 @@ class Engine:
 
     def invalidate(self):
         """Forget the cached prepare() / decode cache.  prepare() keys its cache on (data_ptr, tensor._version, shapes,
-        weights version): writes that do not bump _version (t.data.copy_, DLPack / custom-kernel writes into the same
+        weights generation): writes that do not bump _version (t.data.copy_, DLPack / custom-kernel writes into the same
         buffer, p.data edits of the weights) are invisible to it - call this after such a write."""
         self._prep_key = None
         self._cache_key = None
@@ -206,7 +221,7 @@ class Engine:
             raise RuntimeError("feature size %d != det_feat_size %d" % (det.size(2), self.dims.det_feat_size))
         B, R0, _ = det.shape
         _, L, R, _ = regions.shape
-        key = (det.data_ptr(), det._version, regions.data_ptr(), regions._version, B, R0, L, R, beam,
+        key = (det.data_ptr(), _ver(det), regions.data_ptr(), _ver(regions), B, R0, L, R, beam,
                self._bound_ptrs, weights_version, rows_bound)
         if key == self._prep_key:
             return B
@@ -247,8 +262,8 @@ class Engine:
             if not row_img.is_cuda or row_img.dtype != torch.int32 or row_img.numel() != B:
                 raise RuntimeError("row_img must be an int32 GPU tensor with one entry per row of slot_idx")
             row_img = row_img.contiguous()
-        key = ("idx", det.data_ptr(), det._version, bank.data_ptr(), bank._version, slot_idx.data_ptr(), slot_idx._version,
-               None if row_img is None else (row_img.data_ptr(), row_img._version), B, n_img, R0, Rb, L, R, beam,
+        key = ("idx", det.data_ptr(), _ver(det), bank.data_ptr(), _ver(bank), slot_idx.data_ptr(), _ver(slot_idx),
+               None if row_img is None else (row_img.data_ptr(), _ver(row_img)), B, n_img, R0, Rb, L, R, beam,
                self._bound_ptrs, weights_version, rows_bound)
         if key == self._prep_key:
             return B

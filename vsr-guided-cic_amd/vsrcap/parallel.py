@@ -103,6 +103,7 @@ class DataParallelStep:
             raise ValueError("exchange_dtype must be torch.float32 or torch.bfloat16")
         self.exchange_dtype = exchange_dtype
         self._wire = None                  # bf16 image of the flat gradient buffer (exchange_dtype = bf16, caller-supplied SUM)
+        self._cap_key, self._cap = None, 0
         self._wires = {}                   # shared bf16 staging (send, recv, out) + fp32 shard of the all-to-all exchange, sized for the largest bucket
         if self.model is not None:
             from . import _lib
@@ -132,6 +133,14 @@ class DataParallelStep:
 
     def _world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _wire_cap(self, world):
+        """elements of the shared bf16 staging buffers: the largest bucket, rounded up to whole shards (computed once per world size)"""
+        if self._cap_key != (world, id(self.grads)):
+            g = self.grads
+            self._cap = max(world * ((hi - lo + world - 1) // world) for lo, hi in g.ranges)
+            self._cap_key = (world, id(self.grads))
+        return self._cap
 
     def _sum(self, t):
         if self._world() > 1:
@@ -171,7 +180,10 @@ class DataParallelStep:
         world = self._world()
         n = buf.numel()
         shard = (n + world - 1) // world
-        cap = max(world * ((g.bucket(b).numel() + world - 1) // world) for b in range(len(g.ranges)))
+        cap = self._wire_cap(world)
+        if world * shard > cap:
+            raise RuntimeError("bf16 exchange: a buffer of %d elements is larger than the largest gradient bucket (%d): "
+                               "_exchange_bucket takes slices of this step's flat gradient buffer only" % (n, cap))
         key = (cap, world, buf.device)
         if self._wires.get("key") != key:
             self._wires = {"key": key,
@@ -221,6 +233,13 @@ class DataParallelStep:
                 w.wait()                     # RCCL's internal stream -> side stream
         main.wait_stream(self.comm_stream)   # the optimizer step (main stream) needs every bucket
 
+    def _optimizer_step(self):
+        self.opt.step()
+        if self.model is not None:
+            # the weights moved: whatever the library derived from them (fp16-pair images, bf16 copies, decode cache) is redone by the
+            # next call - said explicitly, not inferred from Tensor._version (fused optimizers leave it untouched)
+            self.model.invalidate_cache()
+
     def xe_step(self, det, captions, ctrl_seq, gate_gts):
         out, gate = self.forward_fn(det, captions, ctrl_seq)
         V = out.shape[-1]
@@ -236,7 +255,7 @@ class DataParallelStep:
         loss_gate = nll_g / counts[1].to(nll_g.dtype)
         loss = loss_cap + 4 * loss_gate                      # this rank's share of the global loss
         self._backward_and_exchange(loss)
-        self.opt.step()
+        self._optimizer_step()
         stats = torch.stack([loss.detach(), loss_cap.detach(), loss_gate.detach()]).double()
         return self._sum(stats)                              # global loss, loss_cap, loss_gate
 
@@ -249,5 +268,5 @@ class DataParallelStep:
         per = -(lp_w.mean(-1) + lp_g.mean(-1)) * (reward - baseline).to(lp_w.dtype)
         loss = per.sum() / n[0].to(per.dtype)
         self._backward_and_exchange(loss)
-        self.opt.step()
+        self._optimizer_step()
         return self._sum(loss.detach().double().reshape(1))[0]
