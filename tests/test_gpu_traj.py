@@ -68,12 +68,15 @@ def test_five_xe_steps_follow_the_reference(name, opt_kw):
     np.testing.assert_allclose(held, g["heldout_losses"], atol=1e-4, rtol=2e-5)
 
 
-def test_five_xe_steps_bf16_deviation_stated():
+def test_five_xe_steps_bf16_deviation_stated(gemm_flavour):
     """bf16 is not a parity mode: the trajectory's deviation from the reference is STATED (observed x 1.5), with the fused optimizer
     bench.py uses; a run on stale copies would be off by whole units from step 2 on"""
+    if gemm_flavour not in (None, "f16x2"):
+        pytest.skip("picks its own compute dtype: run once")
     meta, g, losses, dn, held = _run("g14_xe_traj", dict(fused=True), dtype="bf16")
     d = np.abs(losses - g["losses"])
     print("bf16 trajectory deviation per step (total, cap, gate):", d.tolist(), "held-out:", np.abs(held - g["heldout_losses"]).tolist())
-    assert d[:, 1].max() < 5e-3                       # caption loss
-    assert (d[:, 2] / np.maximum(1.0, g["losses"][:, 2])).max() < 5e-2       # gate loss, relative where it has jumped
+    # observed on the box (round 6): caption loss <= 7.6e-6, gate loss <= 1.8e-2 absolute = 5.1e-3 of its value where it has jumped
+    assert d[:, 1].max() < 5e-5                       # caption loss
+    assert (d[:, 2] / np.maximum(1.0, g["losses"][:, 2])).max() < 1e-2       # gate loss, relative where it has jumped
     np.testing.assert_allclose(dn, g["delta_norm"], rtol=5e-2)
