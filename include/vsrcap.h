@@ -241,11 +241,17 @@ int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const int64_t* slot
                       float* logp_gates, void* train_workspace, size_t train_workspace_bytes, void* stream);
 int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, const float* grad_logp_gates, const vsr_weights* grads,
                        void* stream);
-/* The handle holds ONE saved forward at a time (the reference runs under eager autograd and has no such limit).
- * vsr_train_generation() identifies it (0 = none, changes with every vsr_train_forward and every vsr_prepare*):
- * a caller that may have several forwards alive (loss = l1 + l2, XE forward + sample_rl in one step, a second
- * backward) records the value after its forward and refuses to call vsr_train_backward when it has changed. */
+/* More than one live forward (the reference runs under eager autograd: two forwards then (l1 + l2).backward(), micro-batches, a decode
+ * call between a forward and its backward all just work, CaptioningModel.py:22-36).  A forward's saved state lives in the TWO caller
+ * buffers it was given - the vsr_prepare*() workspace and the training workspace - and stays differentiable for as long as no later
+ * vsr_prepare*() / vsr_train_forward() is handed memory that overlaps either of them (and the GEMM flavour / weight binding does not
+ * change).  vsr_train_generation() identifies the forward just taken (0 = none; strictly increasing per handle).  A caller with
+ * several forwards alive gives each its own pair of buffers, records the generation after each forward, and calls
+ * vsr_train_select(h, generation, stream) before vsr_train_backward(): it makes that forward the handle's current one again (pointers,
+ * image registrations, the per-batch rows of the f16x2 exponent table) or fails if its buffers have been reused.  A caller with ONE
+ * pair of buffers (the round-1..5 contract) sees the old behaviour: the next vsr_prepare*() voids the saved forward. */
 int64_t vsr_train_generation(const vsr_handle* h);
+int vsr_train_select(vsr_handle* h, int64_t generation, void* stream);
 /* Data-parallel hook (the reference is single-device, coco_scripts/train.py:22): vsr_train_backward finishes the
  * 28 gradients in buckets, largest first, and records a HIP event after each.  bucket_of[i] = bucket of gradient i (field
  * order of vsr_weights), static.  vsr_train_wait_bucket() makes `stream` wait on the device for one bucket of the LAST

@@ -28,7 +28,7 @@ def pytest_configure(config):
 FLAVOURS = ("f16x2", "f32x3", "f32")
 DUAL_FLAVOUR_MODULES = ("test_gpu_parity", "test_gpu_configs", "test_gpu_train", "test_gpu_regions", "test_aa_gpu_dp",
                         "test_gpu_headline", "test_gpu_train_indexed", "test_gpu_real_shapes", "test_gpu_weight_generation",
-                        "test_gpu_traj")
+                        "test_gpu_traj", "test_gpu_live_forwards")
 
 
 def pytest_generate_tests(metafunc):

@@ -262,19 +262,7 @@ def test_freeze_branch_tokens_and_logprobs():
 
 
 # ------------------------------------------------------------------ input contracts (advisor findings)
-def test_two_forwards_then_backward_of_the_first_raises():
-    meta, _ = load_golden("g1_xe_small")
-    cfg = meta["cfg"]
-    m, _ = _model(meta, gains=meta["gains"])
-    det, ctrl_seq, caps, gts = helpers.train_inputs(cfg, meta["seed"])
-    m.train()
-    out1, gate1 = m((det.to(DEV),), (caps.to(DEV), ctrl_seq.to(DEV)))
-    out2, gate2 = m((det.to(DEV),), (caps.roll(1, 0).to(DEV), ctrl_seq.to(DEV)))
-    l2 = vo.xe_loss(out2, gate2, caps.roll(1, 0).to(DEV), gts.to(DEV))[0]
-    l2.backward()                                                # the live forward: fine
-    l1 = vo.xe_loss(out1, gate1, caps.to(DEV), gts.to(DEV))[0]
-    with pytest.raises(RuntimeError, match="ONE training forward"):
-        l1.backward()
+# (two forwards then a backward of the first: raised in rounds 1-5, works since round 6 - tests/test_gpu_live_forwards.py)
 
 
 def test_teacher_forcing_with_more_slots_than_steps():

@@ -13,11 +13,11 @@
 // so every matrix product of the backward pass runs on the same stream-K fp32-MFMA kernel as the forward pass.
 
 constexpr int VSR_GRAD_BUCKETS = 5;
-struct TrainCtx {
-    hipEvent_t bucket_ev[VSR_GRAD_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // recorded by vsr_train_backward
-    bool buckets_recorded = false;
-    ~TrainCtx() { for (hipEvent_t e : bucket_ev) if (e) (void)hipEventDestroy(e); }
+struct TrainCtx {                      // (plain data + two vectors: copied into SavedForwards)
     bool valid = false;
+    const char* tws_lo = nullptr;      // the training workspace this forward was carved into
+    size_t tws_bytes = 0;
+    int* h2_stash = nullptr;           // f16x2: the per-batch exponents / bounds of the handle's table as they were for THIS forward (8 ints)
     long long generation = 0;          // bumped by every vsr_train_forward: identifies the saved forward a backward belongs to
     int B = 0, T = 0, TB = 0, TBp = 0, Bp = 0, RLp = 0;
     const float* logp_w = nullptr;     // caller's (B,T,V) output of the forward, needed by the backward
@@ -69,6 +69,7 @@ static size_t carve_train(const vsr_handle* h, TrainCtx& t, char* base) {
     t.sents = b.take<float>(TB * D); t.atts = b.take<float>(TB * D); t.alphas = b.take<float>(TB * R1);
     t.x_all = b.take<float>(TB * E);
     t.word32 = b.take<int>(TB); t.slot32 = b.take<int>(TB); t.rows_bt = b.take<int>(TB);
+    t.h2_stash = b.take<int>(8);
     t.dlogits = b.take<float>(TB * up4(V)); t.dh2_voc = b.take<float>(TB * H);
     t.dpre1 = b.take<float>(TB * 6 * H); t.dpre2 = b.take<float>(TB * 4 * H);
     t.dhA_all = b.take<float>(TB * A); t.dsent_all = b.take<float>(TB * D); t.dsa_all = b.take<float>(TB * A); t.dga_all = b.take<float>(TB * A);
@@ -204,6 +205,63 @@ static void transpose(vsr_handle* h, hipStream_t s, const float* in, long long l
     else hipLaunchKernelGGL((k_transpose_t<false, 0>), grid, block, 0, s, in, ld_in, (const int*)nullptr, R, C, out, ld_out, (uint16_t*)nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------- more than one live forward
+// The reference runs under eager autograd: two forwards and then (l1 + l2).backward(), or a decode between a forward and its backward,
+// just work (CaptioningModel.py:22-36).  Here a forward's saved state is the pair (Ctx, TrainCtx) of pointers into TWO caller buffers:
+// the vsr_prepare*() workspace and the training workspace.  Every vsr_train_forward files a copy of that pair under its generation; a
+// later vsr_prepare*() / vsr_train_forward drops the copies whose buffers it is about to overwrite (address overlap) and keeps the
+// rest.  A caller that gives its second forward OTHER buffers can therefore still differentiate the first: vsr_train_select() makes a
+// filed forward the handle's current one again (pointers, image registrations, the per-batch rows of the f16x2 exponent table).
+struct SavedForward { Ctx c; TrainCtx t; const char* ws_lo; size_t ws_bytes; };
+struct SavedForwards { std::vector<SavedForward> v; };
+static SavedForwards* new_saved_forwards() { return new SavedForwards(); }
+static void free_saved_forwards(SavedForwards* s) { delete s; }
+static void drop_saved_forwards(SavedForwards* s) { if (s) s->v.clear(); }
+static bool ranges_overlap(const char* a, size_t na, const char* b, size_t nb) { return a && b && a < b + nb && b < a + na; }
+static void drop_saved_forwards_in(SavedForwards* s, const void* lo, size_t bytes) {
+    if (!s) return;
+    const char* p = reinterpret_cast<const char*>(lo);
+    for (size_t i = s->v.size(); i-- > 0;)
+        if (ranges_overlap(p, bytes, s->v[i].ws_lo, s->v[i].ws_bytes) || ranges_overlap(p, bytes, s->v[i].t.tws_lo, s->v[i].t.tws_bytes))
+            s->v.erase(s->v.begin() + i);
+}
+// the images of a training workspace's transposed operands: the GEMM builder finds them by address
+static void register_train_images(vsr_handle* h, const TrainCtx& t) {
+    h->b16.resize(h->b16_weights);
+    for (const TrainCtx::Twin& tw : t.twins) h->b16.push_back(Bf16Range{tw.f, tw.f + tw.n, tw.b});
+    h->h2t.clear();
+    h->h2t_only = false;
+    for (const TrainCtx::Img& im : t.imgs) h->h2t.push_back(H2Range{im.f, im.f + im.n, t.h2img + im.off, im.slot});
+}
+// rows of the f16x2 exponent / bound tables that vsr_prepare*() fills per batch (H2A_REGION, H2A_DET, H2A_ATT): dir 0 = table -> stash
+__global__ void k_h2_stash(int* __restrict__ exps, unsigned* __restrict__ bounds, int* __restrict__ stash, int dir) {
+    const int i = threadIdx.x;
+    if (i >= 3) return;
+    if (dir == 0) { stash[i] = exps[H2A_REGION + i]; stash[4 + i] = (int)bounds[H2A_REGION + i]; }
+    else { exps[H2A_REGION + i] = stash[i]; bounds[H2A_REGION + i] = (unsigned)stash[4 + i]; }
+}
+static_assert(H2A_DET == H2A_REGION + 1 && H2A_ATT == H2A_REGION + 2, "k_h2_stash walks three consecutive slots");
+
+extern "C" int vsr_train_select(vsr_handle* h, int64_t generation, void* stream) {
+    if (!h || !h->tc) return fail("vsr_train_select: null handle");
+    if (generation <= 0) return fail("vsr_train_select: generation %lld", (long long)generation);
+    if (h->tc->valid && h->tc->generation == generation && h->prepared) return 0;
+    for (const SavedForward& sf : h->saved->v)
+        if (sf.t.generation == generation) {
+            h->c = sf.c;
+            *h->tc = sf.t;
+            h->tc->valid = true;
+            h->ws_lo = sf.ws_lo; h->ws_bytes = sf.ws_bytes;
+            h->prepared = true;
+            register_train_images(h, *h->tc);
+            if (h->h2_on && h->tc->h2_stash) hipLaunchKernelGGL(k_h2_stash, dim3(1), dim3(64), 0, (hipStream_t)stream, h->h2_exps, h->h2_bounds, h->tc->h2_stash, 1);
+            LAUNCHCHK();
+            return 0;
+        }
+    return fail("vsr_train_select: the forward pass of generation %lld is gone (a later vsr_prepare*() / vsr_train_forward was given its "
+                "workspaces, or the GEMM flavour / the weight binding changed)", (long long)generation);
+}
+
 extern "C" size_t vsr_train_workspace_bytes(const vsr_handle* h, int32_t B, int32_t T) {
     if (!h || !h->prepared || B != h->c.B || T <= 0) return 0;
     TrainCtx t;
@@ -232,11 +290,9 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     t.B = B; t.T = T;
     const size_t need = carve_train(h, t, reinterpret_cast<char*>(train_ws));
     if (need > train_ws_bytes) return fail("vsr_train_forward: training workspace too small (%zu < %zu)", train_ws_bytes, need);
-    h->b16.resize(h->b16_weights);                         // (re)register the bf16 twins of this workspace
-    for (const TrainCtx::Twin& tw : t.twins) h->b16.push_back(Bf16Range{tw.f, tw.f + tw.n, tw.b});
-    h->h2t.clear();                                        // ... and the fp16-pair images
-    h->h2t_only = false;
-    for (const TrainCtx::Img& im : t.imgs) h->h2t.push_back(H2Range{im.f, im.f + im.n, t.h2img + im.off, im.slot});
+    drop_saved_forwards_in(h->saved, train_ws, need);       // forwards filed in THIS buffer are overwritten now
+    t.tws_lo = reinterpret_cast<const char*>(train_ws); t.tws_bytes = need;
+    register_train_images(h, t);                           // the bf16 twins / fp16-pair images of this workspace's transposed operands
     const int TB = T * B;
     const size_t BH = (size_t)B * H;
     HIPCHK(hipMemsetAsync(t.h1s, 0, BH * sizeof(float), s));
@@ -383,7 +439,10 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     t.logp_w = logp_words;
     t.logp_g = logp_gates;
     t.valid = true;
-    ++t.generation;
+    t.generation = ++h->gen_counter;
+    if (h->h2_on) hipLaunchKernelGGL(k_h2_stash, dim3(1), dim3(64), 0, s, h->h2_exps, h->h2_bounds, t.h2_stash, 0);
+    LAUNCHCHK();
+    h->saved->v.push_back(SavedForward{c, t, h->ws_lo, h->ws_bytes});
     return 0;
 }
 
@@ -646,8 +705,8 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     // Gradients are finished bucket by bucket, largest first, and an event is recorded after each bucket
     // (vsr_train_bucket_map / vsr_train_wait_bucket): a data-parallel caller starts the all-reduce of a finished bucket on
     // a side stream while the remaining weight-gradient GEMMs run.  The last bucket is the smallest (14 MB).
-    if (!t.bucket_ev[0])
-        for (int i = 0; i < VSR_GRAD_BUCKETS; ++i) HIPCHK(hipEventCreateWithFlags(&t.bucket_ev[i], hipEventDisableTiming));
+    if (!h->bucket_ev[0])
+        for (int i = 0; i < VSR_GRAD_BUCKETS; ++i) HIPCHK(hipEventCreateWithFlags(&h->bucket_ev[i], hipEventDisableTiming));
     // ---- bucket 0: lstm_cell_1.weight_ih / W1_is / W1_ig: row blocks [0,4H), [4H,5H), [5H,6H) of dpre1^T against [h2_prev | vbar | x]
     {
         float* Gw[3] = {G[g_Wih1], G[g_Wis], G[g_Wig]};
@@ -660,7 +719,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             if (gemm_to1(h, t, s, nr[i], E, TBp, dy, TBp, t.tX_x, TBp, Gw[i] + xoff, in1, sa, tyi)) return 1;
         }
     }
-    HIPCHK(hipEventRecord(t.bucket_ev[0], s));
+    HIPCHK(hipEventRecord(h->bucket_ev[0], s));
     // ---- bucket 1: lstm_cell_2
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2, sP2, tyi)) return 1;
     if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2, sP2, tyi)) return 1;
@@ -672,7 +731,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H, sP2, tyi)) return 1;
     colsum(t, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2]);
     HIPCHK(hipMemcpyAsync(G[g_bhh2], G[g_bih2], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipEventRecord(t.bucket_ev[1], s));
+    HIPCHK(hipEventRecord(h->bucket_ev[1], s));
     // ---- bucket 2: out_fc and the embedding
     if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H, dslot(DW_dlogits), tyi)) return 1;
     colsum(t, s, t.dlogits, (long long)Vp, TB, V, G[g_bout]);
@@ -684,7 +743,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         HIPCHK(hipMemsetAsync(G[g_embed], 0, (size_t)V * E * sizeof(float), s));
         hipLaunchKernelGGL(k_embed_grad_rows, dim3(TB), dim3(256), 0, s, t.dx_all, t.word32, TB, E, G[g_embed]);
     }
-    HIPCHK(hipEventRecord(t.bucket_ev[2], s));
+    HIPCHK(hipEventRecord(h->bucket_ev[2], s));
     // ---- bucket 3: the recurrent LSTM1 / sentinel-gate weights, all LSTM1 / gate biases, s_fc, att_va
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H, tyi ? sY1 : sP1, tyi)) return 1;
     if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H, tyi ? sY1 : sP1, tyi)) return 1;
@@ -702,7 +761,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     } else {
         HIPCHK(hipMemsetAsync(G[g_Wva], 0, (size_t)A * D * sizeof(float), s));
     }
-    HIPCHK(hipEventRecord(t.bucket_ev[3], s));
+    HIPCHK(hipEventRecord(h->bucket_ev[3], s));
     // ---- bucket 4 (the tail, 3.5 M floats): W1_hg, att_ha, att_sa, att_ga and the three score vectors
     if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H, tyi ? sY1 : sQ, tyi)) return 1;
     if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H, dslot(DW_step + DY_dhA), tyi)) return 1;
@@ -711,8 +770,8 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     colsum(t, s, t.dwa_rows, (long long)A, TB, A, G[g_wa]);
     colsum(t, s, t.dws_rows, (long long)A, TB, A, G[g_ws]);
     colsum(t, s, t.dwg_rows, (long long)A, TB, A, G[g_wg]);
-    HIPCHK(hipEventRecord(t.bucket_ev[4], s));
-    t.buckets_recorded = true;
+    HIPCHK(hipEventRecord(h->bucket_ev[4], s));
+    h->buckets_recorded = true;
     LAUNCHCHK();
     return 0;
 }
@@ -741,10 +800,9 @@ extern "C" int vsr_train_bucket_map(int32_t* bucket_of, int32_t* n_buckets) {
 // Make `stream` wait (on the device; the host does not block) until bucket `bucket` of the last vsr_train_backward is complete.
 extern "C" int vsr_train_wait_bucket(vsr_handle* h, int32_t bucket, void* stream) {
     if (!h || !h->tc) return fail("vsr_train_wait_bucket: null handle");
-    TrainCtx& t = *h->tc;
     if (bucket < 0 || bucket >= VSR_GRAD_BUCKETS) return fail("vsr_train_wait_bucket: bucket %d not in [0, %d)", bucket, VSR_GRAD_BUCKETS);
-    if (!t.buckets_recorded) return fail("vsr_train_wait_bucket: no backward pass has run on this handle");
-    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, t.bucket_ev[bucket], 0));
+    if (!h->buckets_recorded) return fail("vsr_train_wait_bucket: no backward pass has run on this handle");
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, h->bucket_ev[bucket], 0));
     return 0;
 }
 

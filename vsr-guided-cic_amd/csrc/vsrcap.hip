@@ -92,6 +92,11 @@ struct TrainCtx;
 static TrainCtx* new_train_ctx();
 static void free_train_ctx(TrainCtx*);
 static void invalidate_train_ctx(TrainCtx*);
+struct SavedForwards;                 // the training forwards whose workspaces are still intact (train.inc.h)
+static SavedForwards* new_saved_forwards();
+static void free_saved_forwards(SavedForwards*);
+static void drop_saved_forwards(SavedForwards*);                                            // all of them (a change of GEMM flavour / weights binding)
+static void drop_saved_forwards_in(SavedForwards*, const void* lo, size_t bytes);           // those whose workspaces overlap [lo, lo + bytes)
 
 struct Bf16Range { const float* lo; const float* hi; const uint16_t* b; };   // fp32 matrix [lo, hi) has a bf16 copy at b
 struct H2Range { const float* lo; const float* hi; const float* img; int slot; };   // ... an fp16-pair image (gemm_h2.h) at img, scale exponent in slot
@@ -102,6 +107,12 @@ enum H2Slot { H2A_NONE = -1, H2A_EMBED = 14, H2A_UNIT = 15, H2A_REGION = 16, H2A
 
 struct vsr_handle {
     TrainCtx* tc = nullptr;
+    SavedForwards* saved = nullptr;
+    hipEvent_t bucket_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // recorded by vsr_train_backward after each gradient bucket
+    bool buckets_recorded = false;
+    long long gen_counter = 0;        // generations of the training forwards: strictly increasing per handle
+    const char* ws_lo = nullptr;      // the workspace the current vsr_prepare*() carved (h->c points into it)
+    size_t ws_bytes = 0;
     // bf16 throughput mode (gemm_bf16.h): off unless vsr_refresh_bf16_weights() has been given a buffer
     bool bf16_on = false;
     // f16x2 flavour (gemm_h2.h): on once vsr_refresh_h2_weights() has been given a buffer, and only together with x3_on (a launch
@@ -582,6 +593,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     vsr_handle* h = new vsr_handle();
     h->d = d;
     h->tc = new_train_ctx();
+    h->saved = new_saved_forwards();
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) {
@@ -629,6 +641,8 @@ extern "C" void vsr_destroy(vsr_handle* h) {
     if (h->ev_count) (void)hipEventDestroy(h->ev_count);
     if (h->host_back) (void)hipHostFree(h->host_back);
     free_train_ctx(h->tc);
+    free_saved_forwards(h->saved);
+    for (hipEvent_t e : h->bucket_ev) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -679,6 +693,7 @@ extern "C" int vsr_bind_weights(vsr_handle* h, const vsr_weights* w) {
         if (!p[i]) return fail("vsr_bind_weights: weight pointer %zu is null", i);
     h->w = *w;
     h->bound = true;
+    invalidate_train_ctx(h->tc); drop_saved_forwards(h->saved);     // saved forwards were taken with the old tensors
     h->xproj = nullptr;               // a cache built for other weight pointers is void
     if (h->bf16_on) {                 // ... and so are the bf16 copies: back to fp32 until vsr_refresh_bf16_weights is called again
         h->bf16_on = false;
@@ -759,7 +774,7 @@ extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t byte
         h->b16.erase(h->b16.begin(), h->b16.begin() + h->b16_weights);     // the weight copies only: the training workspace's twins stay registered
         h->b16_weights = 0;
         h->xproj = nullptr;                                 // a decode cache built in the other precision is void
-        invalidate_train_ctx(h->tc);                        // a saved forward of the other precision cannot be differentiated in this one
+        invalidate_train_ctx(h->tc); drop_saved_forwards(h->saved);      // a saved forward of the other precision cannot be differentiated in this one
         return 0;
     }
     if (!h->bound) return fail("vsr_refresh_bf16_weights: weights not bound");
@@ -785,7 +800,7 @@ extern "C" int vsr_refresh_bf16_weights(vsr_handle* h, void* buffer, size_t byte
     LAUNCHCHK();
     if (!h->bf16_on) {
         h->xproj = nullptr;
-        invalidate_train_ctx(h->tc);                        // (as above: the GEMM precision of a saved forward and its backward must match)
+        invalidate_train_ctx(h->tc); drop_saved_forwards(h->saved);      // (as above: the GEMM precision of a saved forward and its backward must match)
     }
     h->bf16_on = true;
     return 0;
@@ -828,7 +843,7 @@ __global__ void k_h2_prepare_exps(const unsigned* __restrict__ bounds, int R0, i
 extern "C" int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream) {
     if (!h) return fail("vsr_refresh_h2_weights: null handle");
     if (!buffer) {                                          // back to f32x3 for every launch
-        if (h->h2_on) { h->xproj = nullptr; invalidate_train_ctx(h->tc); h->prepared = false; }
+        if (h->h2_on) { h->xproj = nullptr; invalidate_train_ctx(h->tc); drop_saved_forwards(h->saved); h->prepared = false; }
         h->h2_on = false;
         h->h2.clear(); h->h2t.clear();
         return 0;
@@ -892,7 +907,7 @@ extern "C" int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes,
     hipLaunchKernelGGL(k_f32_to_h2_multi, dim3(blocks), dim3(256), 0, s, mc, reinterpret_cast<uint32_t*>(out), exps);
     LAUNCHCHK();
     h->h2_exps = exps; h->h2_bounds = bounds;
-    if (!h->h2_on) { h->xproj = nullptr; invalidate_train_ctx(h->tc); }
+    if (!h->h2_on) { h->xproj = nullptr; invalidate_train_ctx(h->tc); drop_saved_forwards(h->saved); }
     h->prepared = false;              // the bounds of the region / detection operands are measured by vsr_prepare*()
     h->h2_on = true;
     return 0;
@@ -906,7 +921,7 @@ extern "C" int vsr_set_gemm_mode(vsr_handle* h, int32_t mode) {
     if (mode != 0 && mode != 1) return fail("vsr_set_gemm_mode: mode %d not in {0, 1}", mode);
     if (h->x3_on != (mode == 1)) {
         h->xproj = nullptr;                                // the decode cache is rebuilt in the new flavour,
-        invalidate_train_ctx(h->tc);                       // a saved forward of the other flavour is not differentiated in this one,
+        invalidate_train_ctx(h->tc); drop_saved_forwards(h->saved);     // a saved forward of the other flavour is not differentiated in this one,
         h->prepared = false;                               // and the hoisted projections are redone: call vsr_prepare*() after a switch
     }
     h->x3_on = mode == 1;
@@ -969,7 +984,11 @@ static int prepare_impl(vsr_handle* h, const float* det, int B, int R0, const fl
     c.ridx = c.ridx_buf;
     c.rows_are_images = indexed && row_img == nullptr && n_img == B;
     h->prepared = false;
-    invalidate_train_ctx(h->tc);       // a saved forward refers to the hoisted tensors of the previous prepare()
+    // h->c is rewritten: the CURRENT saved forward (if any) goes with it unless it lives in another workspace - forwards saved in
+    // workspaces this call does not touch stay differentiable (vsr_train_select)
+    invalidate_train_ctx(h->tc);
+    drop_saved_forwards_in(h->saved, workspace, need);
+    h->ws_lo = reinterpret_cast<const char*>(workspace); h->ws_bytes = need;
 
     // region-row masks, then the list of NON-PADDING rows att_va has to run over (att_va(0) = 0).  Their count has to
     // reach the host to size that launch: the one place where this library waits, and it waits for an EVENT behind the

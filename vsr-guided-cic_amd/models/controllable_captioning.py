@@ -241,13 +241,14 @@ class ControllableCaptioningModel(CaptioningModel):
         from vsrcap.regions import IndexedRegions
         return regions.slot_idx.size(1) if isinstance(regions, IndexedRegions) else regions.size(1)
 
-    def _prepare(self, eng, det, regions, beam):
+    def _prepare(self, eng, det, regions, beam, for_training=False):
         """Hoisted per-image work for either region format: the reference's dense (B,L,R,D) tensor, or
         vsrcap.regions.IndexedRegions (index lists into the image's feature bank; training too when every row is its own image)."""
         from vsrcap.regions import IndexedRegions
         if isinstance(regions, IndexedRegions):
-            return eng.prepare_indexed(det, regions.bank, regions.slot_idx, regions.row_img, beam, self._weights_version(), self.valid_rows_bound)
-        return eng.prepare(det, regions, beam, self._weights_version(), self.valid_rows_bound)
+            return eng.prepare_indexed(det, regions.bank, regions.slot_idx, regions.row_img, beam, self._weights_version(), self.valid_rows_bound,
+                                       for_training=for_training)
+        return eng.prepare(det, regions, beam, self._weights_version(), self.valid_rows_bound, for_training=for_training)
 
     # ------------------------------------------------------------------ loops (CaptioningModel hooks)
     def _run_forward(self, statics, seqs):
@@ -261,7 +262,7 @@ class ControllableCaptioningModel(CaptioningModel):
             if isinstance(ctrl_seq, IndexedRegions) and ctrl_seq.row_img is not None:
                 raise RuntimeError("training on IndexedRegions needs one decoder row per image (row_img=None), as the reference's "
                                    "training batches have; with a row -> image map train on regions.dense()")
-            B = self._prepare(eng, det, ctrl_seq, 1)
+            B = self._prepare(eng, det, ctrl_seq, 1, for_training=True)
             from vsrcap.train import xe_forward_with_grad
             return xe_forward_with_grad(self, eng, det, captions, ctrl_seq)
         B = self._prepare(eng, det, ctrl_seq, 1)
@@ -286,7 +287,7 @@ class ControllableCaptioningModel(CaptioningModel):
         from vsrcap.regions import IndexedRegions
         if with_grad and isinstance(ctrl, IndexedRegions) and ctrl.row_img is not None:
             raise RuntimeError("sample_rl with gradients on IndexedRegions needs one decoder row per image (row_img=None)")
-        B = self._prepare(eng, det, ctrl, 1)
+        B = self._prepare(eng, det, ctrl, 1, for_training=with_grad)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             # data-parallel ranks that called torch.manual_seed(s) with the same s would otherwise draw IDENTICAL Gumbel /

@@ -91,6 +91,7 @@ SIGNATURES = {
     "vsr_train_forward": (I32, [P, P, P, I32, P, P, P, SZ, P]),
     "vsr_train_backward": (I32, [P, P, P, C.POINTER(VsrWeights), P]),
     "vsr_train_generation": (I64, [P]),
+    "vsr_train_select": (I32, [P, I64, P]),
     "vsr_train_bucket_map": (I32, [C.POINTER(I32), C.POINTER(I32)]),
     "vsr_train_wait_bucket": (I32, [P, I32, P]),
     "vsr_bad_ids": (I32, [P, C.POINTER(I32), P]),

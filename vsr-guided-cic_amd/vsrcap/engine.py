@@ -59,6 +59,33 @@ class _Null:
         return False
 
 
+class ForwardToken:
+    """Lives in the autograd node of one training forward (train._DecoderFn): while it is alive and its forward has not been
+    differentiated, the buffers that forward was saved in are not handed to anyone else."""
+    __slots__ = ("generation", "__weakref__")
+
+    def __init__(self, generation):
+        self.generation = generation
+
+
+class _Slot:
+    """One pair of caller buffers of the C ABI - the vsr_prepare*() workspace and the training workspace - plus the inputs they borrow.
+    A saved training forward lives in exactly one slot (include/vsrcap.h, vsr_train_select)."""
+    __slots__ = ("ws", "tws", "keep", "token", "generation", "differentiated")
+
+    def __init__(self):
+        self.ws = self.tws = self.keep = self.token = None
+        self.generation = 0
+        self.differentiated = True
+
+    def live(self):
+        """holds a forward somebody can still ask the gradient of for the FIRST time"""
+        return self.token is not None and self.token() is not None and not self.differentiated
+
+
+MAX_LIVE_FORWARDS = 8
+
+
 class Engine:
     def __init__(self, dims, device=None):
         """dims: dict with the vsr_dims fields; device: the torch cuda device this handle lives on (one handle per device)."""
@@ -74,11 +101,38 @@ class Engine:
         # library's count of out-of-range ids and raise like nn.Embedding would (costs one stream synchronisation per call)
         self.check_ids = os.environ.get("VSR_CHECK_IDS", "0") not in ("", "0")
         self._bound_ptrs = None
-        self._ws = None
+        self._slots = [_Slot()]          # buffer pairs; more than one only while several training forwards are alive
+        self._slot = self._slots[0]
         self._prep_key = None
-        self._keep = None
         self._verb_dev = None
         self.grad_sink = None       # list of 28 tensors (WEIGHT_FIELDS order): backward writes there and autograd gets no tensors
+
+    # the current slot's buffers under their old names
+    _ws = property(lambda self: self._slot.ws, lambda self, v: setattr(self._slot, "ws", v))
+    _tws = property(lambda self: self._slot.tws, lambda self, v: setattr(self._slot, "tws", v))
+    _keep = property(lambda self: self._slot.keep, lambda self, v: setattr(self._slot, "keep", v))
+
+    def _claim_slot(self):
+        """Called before a vsr_prepare*() that will overwrite the current slot's workspace: if a live forward is saved there, move to
+        a free slot (one whose forward is gone or already differentiated), or open a new one.  The reference has no such limit at
+        all (eager autograd); MAX_LIVE_FORWARDS pairs of buffers is where this build stops."""
+        if not self._slot.live():
+            return
+        for sl in self._slots:
+            if not sl.live():
+                self._slot = sl
+                self._prep_key = None
+                return
+        if len(self._slots) >= MAX_LIVE_FORWARDS:
+            raise RuntimeError("%d training forwards of this model are alive and not yet differentiated: each holds its own workspaces "
+                               "(~GBs at batch 100). Call backward() on some of them (or drop their outputs) before the next forward."
+                               % len(self._slots))
+        self._slot = _Slot()
+        self._slots.append(self._slot)
+        self._prep_key = None
+
+    def live_forwards(self):
+        return sum(1 for sl in self._slots if sl.live())
 
     def __del__(self):
         try:
@@ -210,9 +264,11 @@ class Engine:
 
     # ------------------------------------------------------------------ hoisted statics
     @_on_device
-    def prepare(self, det, regions, beam, weights_version=None, rows_bound=None):
+    def prepare(self, det, regions, beam, weights_version=None, rows_bound=None, for_training=False):
         """rows_bound: an upper bound on the non-padding region rows the caller knows on the host (None: the library reads the
-        count back - its one synchronisation; include/vsrcap.h, vsr_set_valid_rows_bound)"""
+        count back - its one synchronisation; include/vsrcap.h, vsr_set_valid_rows_bound).
+        for_training: a training forward follows (it overwrites the slot's training workspace): never served from the cache of a slot
+        that holds a live forward"""
         det = _f32(det, "detections")
         regions = _f32(regions, "region sequences")
         if det.dim() != 3 or regions.dim() != 4 or det.size(0) != regions.size(0) or det.size(2) != regions.size(3):
@@ -223,8 +279,9 @@ class Engine:
         _, L, R, _ = regions.shape
         key = (det.data_ptr(), _ver(det), regions.data_ptr(), _ver(regions), B, R0, L, R, beam,
                self._bound_ptrs, weights_version, rows_bound)
-        if key == self._prep_key:
+        if key == self._prep_key and not (for_training and self._slot.live()):
             return B
+        self._claim_slot()
         _lib.check(self.lib.vsr_set_valid_rows_bound(self.h, int(rows_bound or 0)))
         need = self.lib.vsr_workspace_bytes(self.h, B, R0, L, R, beam)
         if need == 0:
@@ -239,7 +296,7 @@ class Engine:
         return B
 
     @_on_device
-    def prepare_indexed(self, det, bank, slot_idx, row_img, beam, weights_version=None, rows_bound=None):
+    def prepare_indexed(self, det, bank, slot_idx, row_img, beam, weights_version=None, rows_bound=None, for_training=False):
         """Index-list region format (include/vsrcap.h, vsr_prepare_indexed): det (n_img,R0,D), bank (n_img,Rb,D),
         slot_idx (B,L,R) int32 rows of the row's image bank (-1 = padding), row_img (B) int32 or None."""
         det = _f32(det, "detections")
@@ -265,8 +322,9 @@ class Engine:
         key = ("idx", det.data_ptr(), _ver(det), bank.data_ptr(), _ver(bank), slot_idx.data_ptr(), _ver(slot_idx),
                None if row_img is None else (row_img.data_ptr(), _ver(row_img)), B, n_img, R0, Rb, L, R, beam,
                self._bound_ptrs, weights_version, rows_bound)
-        if key == self._prep_key:
+        if key == self._prep_key and not (for_training and self._slot.live()):
             return B
+        self._claim_slot()
         _lib.check(self.lib.vsr_set_valid_rows_bound(self.h, int(rows_bound or 0)))
         need = self.lib.vsr_workspace_bytes_indexed(self.h, B, R0, n_img, Rb, L, R, beam)
         if need == 0:
@@ -317,10 +375,23 @@ class Engine:
             self._tws = torch.empty(need, dtype=torch.uint8, device=device)
         out = torch.empty(B, T, V, dtype=torch.float32, device=device)
         gate = torch.empty(B, T, 2, dtype=torch.float32, device=device)
+        if self._slot.live():
+            raise RuntimeError("internal: training forward into a slot that holds a live forward (prepare(for_training=True) first)")
         _lib.check(self.lib.vsr_train_forward(self.h, _ptr(word_in), _ptr(slots), T, _ptr(out), _ptr(gate), _ptr(self._tws),
                                               self._tws.numel(), self._stream(device)))
+        self._slot.generation = self.train_generation()
+        self._slot.token = None
+        self._slot.differentiated = True      # (until train.py attaches the autograd node's token: note_forward)
         self.raise_on_bad_ids(device, "train_forward")
         return out, gate
+
+    def note_forward(self):
+        """the autograd node of the forward just taken: returns the token that keeps its buffers reserved"""
+        import weakref
+        tok = ForwardToken(self._slot.generation)
+        self._slot.token = weakref.ref(tok)
+        self._slot.differentiated = False
+        return tok
 
     def train_generation(self):
         """identity of the forward pass saved in the handle (0 = none): see vsr_train_generation in include/vsrcap.h"""
@@ -332,12 +403,22 @@ class Engine:
         generation: train_generation() recorded right after the forward this backward belongs to.
         into: optional list of 28 caller tensors (e.g. views of ONE flat buffer, parallel.FlatGrads) the library writes
         the gradients to instead of fresh allocations."""
-        if generation is not None and generation != self.train_generation():
-            raise RuntimeError(
-                "backward of a forward pass whose saved activations are gone: the handle keeps ONE training forward at a "
-                "time (a later forward / sample_rl(grad) / prepare() on this model replaced it, or this graph was already "
-                "differentiated into a new forward). Call backward() before the next forward, or accumulate gradients "
-                "over separate forward+backward pairs instead of loss = l1 + l2.")
+        if generation is not None:
+            # several forwards may be alive (each in its own slot): make this one the handle's current forward again
+            if self.lib.vsr_train_select(self.h, int(generation), self._stream(device)) != 0:
+                raise RuntimeError(
+                    "backward of a forward pass whose saved activations are gone (%s). A forward stays differentiable until its "
+                    "buffers are reused: that happens once it HAS been differentiated (a second backward needs a new forward - "
+                    "retain_graph=True is not supported across a later forward), when more than %d forwards are alive, or when "
+                    "the compute dtype / the parameters' storage changed in between."
+                    % (self.lib.vsr_last_error().decode(), MAX_LIVE_FORWARDS))
+            if self._slot.generation != generation:
+                for sl in self._slots:
+                    if sl.generation == generation:
+                        self._slot = sl
+                        self._prep_key = None           # the handle's hoisted state is this slot's now
+                        break
+            self._slot.differentiated = True
         grad_out = _f32(grad_out, "grad of word log-probs")
         grad_gate = _f32(grad_gate, "grad of gate log-probs")
         if into is not None:

@@ -17,7 +17,8 @@ class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eng, B, device, word_in, slots, *params):
         out, gate = eng.train_forward(B, device, word_in, slots)
-        ctx.generation = eng.train_generation()    # the handle keeps ONE saved forward: backward checks it is still this one
+        ctx.generation = eng.train_generation()    # identifies this forward among the live ones (include/vsrcap.h, vsr_train_select)
+        ctx.token = eng.note_forward()             # while this node is alive and not differentiated, its buffers are not reused
         ctx.eng = eng
         ctx.device = device
         ctx.shapes = [tuple(p.shape) for p in params]
