@@ -140,7 +140,7 @@ def test_bf16_mode_refreshes_its_copies_under_a_fused_optimizer(gemm_flavour):
         m = helpers.build_model(cfg, w, DEV).set_compute_dtype("bf16")
         runs.append(_train(m, OPTS["adam"](**{kind: True}), det, ctrl_seq, caps, gts, 3))
     assert abs(runs[0][1] - runs[0][0]) > 1e-3 and abs(runs[0][2] - runs[0][1]) > 1e-3, "the loss must move: %s" % (runs[0],)
-    np.testing.assert_allclose(runs[0], runs[1], atol=5e-6, rtol=0)
+    np.testing.assert_allclose(runs[0], runs[1], atol=5e-6, rtol=2e-5)      # (1-ulp differences of the two Adam kernels, amplified by the bf16 rounding of the copies)
 
 
 def test_inputs_created_under_inference_mode():

@@ -47,7 +47,7 @@ void gemm_nt_bf16x3_kernel(const GemmArgs args) {
     static_assert(64 * (BN + 4) * 4 <= STAGE_B, "epilogue staging must fit one stage");
 
     const int G = args.G;
-    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);      // grid = 8 * ceil(G / 8)
+    const int g = gemm_wg_of_block(args);      // grid = 8 * ceil(G / 8)
     if (g >= G) return;
     const int it0 = gemm_range_begin(g, args.total_iters, G);
     const int it1 = gemm_range_begin(g + 1, args.total_iters, G);

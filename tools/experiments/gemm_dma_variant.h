@@ -40,7 +40,7 @@ void gemm_nt_f32_dma_kernel(const GemmArgs args) {
     __shared__ __attribute__((aligned(1024))) float smem[3 * STAGE];
 
     const int G = args.G;
-    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
+    const int g = gemm_wg_of_block(args);
     if (g >= G) return;
     const int it0 = gemm_range_begin(g, args.total_iters, G);
     const int it1 = gemm_range_begin(g + 1, args.total_iters, G);

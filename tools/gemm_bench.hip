@@ -157,7 +157,7 @@ struct Builder {
     }
     double flops() const { return gemm_flops(a); }
     void launch(hipStream_t st) {
-        dim3 g(((a.G + 7) / 8) * 8), b(256);
+        dim3 g(gemm_grid(a)), b(256);
 #define R16(TM_) else if (tm == 1600 + TM_ && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 2>), g, dim3(512), 0, st, a); \
                  else if (tm == 1600 + TM_ && tn == 4) hipLaunchKernelGGL((gemm_nt_f32_r16_kernel<TM_, 4>), g, dim3(512), 0, st, a);
         if (tm == 3400) {

@@ -23,7 +23,7 @@ void gemm_nt_b16a_kernel(const GemmArgs args) {
     uint16_t* const sW = smem;
 
     const int G = args.G;
-    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
+    const int g = gemm_wg_of_block(args);
     if (g >= G) return;
     const GemmRange rg = gemm_range(args, g);
     const int it0 = rg.it0, it1 = rg.it1;

@@ -90,7 +90,7 @@ void gemm_nt_bf16w_kernel(const GemmArgs args) {
     auto sB = [&](int buf) { return smem + buf * BUF + BM * B16_ROW; };
 
     const int G = args.G;
-    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
+    const int g = gemm_wg_of_block(args);
     if (g >= G) return;
     const GemmRange rg = gemm_range(args, g);
     const int it0 = rg.it0, it1 = rg.it1;

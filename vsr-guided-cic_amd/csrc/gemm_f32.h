@@ -67,7 +67,25 @@ struct GemmArgs {
     int nslab;           // slabs per tile (S)
     int aligned;         // 0: stream-K ranges (gemm_plan); 1: one k-aligned piece of one tile per workgroup (gemm_plan_aligned)
     const int* exps;     // f16x2 kernels only: device table of scale exponents (GemmSeg::w_exp / a_exp index it)
+    int xcd_chunk;       // 0: ceil(G / 8) workgroups per XCD.  > 0 (aligned plan, gemm_plan_aligned): the workgroups are dealt in whole GROUPS of
+    int xcd_unit;        // xcd_unit (= tiles_m) consecutive numbers, xcd_lo groups per XCD and one more on the first xcd_extra XCDs;
+    int xcd_lo, xcd_extra;   // xcd_chunk = the largest per-XCD count = xcd_unit (xcd_lo + (xcd_extra > 0))
 };
+
+// Workgroup number of this block.  Blocks are dispatched round-robin over the 8 XCDs (block b runs on XCD b & 7); XCD x takes the
+// CONTIGUOUS workgroup numbers [x chunk, (x + 1) chunk): neighbouring tiles share their operand windows in that XCD's L2.
+// Returns G (= "no work") for the padding blocks of the grid.
+__device__ __forceinline__ int gemm_wg_of_block(const GemmArgs& a) {
+    const int i = blockIdx.x >> 3, x = blockIdx.x & 7;
+    if (a.xcd_chunk == 0) {
+        const int ch = (a.G + 7) >> 3;
+        return x * ch + i;                     // (>= G for the padding blocks)
+    }
+    const int mine = a.xcd_unit * (a.xcd_lo + (x < a.xcd_extra ? 1 : 0));
+    const int first = a.xcd_unit * (x * a.xcd_lo + (x < a.xcd_extra ? x : a.xcd_extra));
+    return i < mine ? first + i : a.G;
+}
+inline int gemm_grid(const GemmArgs& a) { return 8 * (a.xcd_chunk ? a.xcd_chunk : (a.G + 7) / 8); }
 
 // tile index -> tile origin: m fastest (the m-tiles of a weight n-tile are neighbours)
 __device__ __forceinline__ void gemm_tile_origin(const GemmProb& P, int tile, int BM, int BN, int& m0, int& n0) {
@@ -130,7 +148,7 @@ void gemm_nt_f32_kernel(const GemmArgs args) {
     auto sB = [&](int buf) { return smem + buf * (BM + BN) * GEMM_LDS + BM * GEMM_LDS; };
 
     const int G = args.G;
-    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);      // grid = 8 * ceil(G / 8)
+    const int g = gemm_wg_of_block(args);      // grid = 8 * ceil(G / 8)
     if (g >= G) return;
     const int it0 = gemm_range_begin(g, args.total_iters, G);
     const int it1 = gemm_range_begin(g + 1, args.total_iters, G);
@@ -391,7 +409,7 @@ void gemm_nt_f32_r16_kernel(const GemmArgs args) {
     auto sB = [&](int buf) { return smem + buf * BUF + BM * GEMM_BK; };
 
     const int G = args.G;
-    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
+    const int g = gemm_wg_of_block(args);
     if (g >= G) return;
     const int it0 = gemm_range_begin(g, args.total_iters, G);
     const int it1 = gemm_range_begin(g + 1, args.total_iters, G);
@@ -667,6 +685,7 @@ inline int gemm_plan(GemmArgs& a, int slots, int min_iters = 8, int BM = 64, int
     if (a.nslab > 8) a.nslab = 8;
     for (int i = 0; i < a.nprob; ++i) a.p[i].nslab = a.nslab;      // (gemm_tight_slabs: fewer for a short-K problem of a merged launch)
     a.aligned = 0;
+    a.xcd_chunk = 0;
     return a.nslab;
 }
 
@@ -719,6 +738,17 @@ inline int gemm_plan_aligned(GemmArgs& a, int slots, int min_iters, int BM, int 
     a.nslab = nslab;
     for (int i = 0; i < a.nprob; ++i) a.p[i].nslab = nslab;       // every problem writes / zero-fills the launch's slab count (gemm_tight_slabs: its own split)
     a.aligned = 1;
+    // XCD dealing in whole m-groups (round 6): workgroups are numbered m-fastest, so tiles_m consecutive numbers are the m-tiles of ONE
+    // weight n-tile at ONE k window.  With ceil(G / 8) numbers per XCD a group straddles two XCDs whenever that is not a multiple of
+    // tiles_m (G = 200, tiles_m = 4: 25 per XCD, every fourth group split) and its weight window is fetched by two L2s.  Deal whole
+    // groups instead - when every problem has the same tiles_m and the larger chunk still fits the XCD's share of the slots.
+    a.xcd_chunk = 0;
+    int u = a.p[0].tiles_m;
+    for (int i = 1; i < a.nprob; ++i) if (a.p[i].tiles_m != u) u = 1;
+    if (u > 1 && g % u == 0) {
+        const int groups = g / u, lo = groups / 8, extra = groups % 8, ch = u * (lo + (extra ? 1 : 0));
+        if (ch <= (slots + 7) / 8) { a.xcd_chunk = ch; a.xcd_unit = u; a.xcd_lo = lo; a.xcd_extra = extra; }
+    }
     return nslab;
 }
 

@@ -24,7 +24,7 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
     int* const s_exp = reinterpret_cast<int*>(smem + NW * STG);      // product exponent of the k-tile in stage s (written by a mover, NW - 1 periods ahead)
 
     const int G = args.G;
-    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
+    const int g = gemm_wg_of_block(args);
     if (g >= G) return;
     const GemmRange rg = gemm_range(args, g);
     const int it0 = rg.it0, it1 = rg.it1;

@@ -59,7 +59,7 @@ void gemm_nt_x3_kernel(const GemmArgs args) {
     __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BUF];
 
     const int G = args.G;
-    const int g = (blockIdx.x & 7) * ((G + 7) >> 3) + (blockIdx.x >> 3);
+    const int g = gemm_wg_of_block(args);
     if (g >= G) return;
     const GemmRange rg = gemm_range(args, g);
     const int it0 = rg.it0, it1 = rg.it1;

@@ -204,6 +204,7 @@ struct vsr_handle {
     int gemm_aligned_min = 8;    // shortest piece, in 64-wide k-tiles (VSR_GEMM_ALIGNED_MIN)
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
     long long rows_bound = 0;    // vsr_set_valid_rows_bound: > 0 = the caller's upper bound on the non-padding region rows; vsr_prepare*() then never waits for the host
+    int xcd_groups = 0;          // VSR_XCD_GROUPS=1: k-aligned plans deal whole m-groups of tiles to an XCD (gemm_plan_aligned).  Measured: 2 % less fabric traffic on the wide kernel, 1.3 % SLOWER end to end (profiles/r06_d_xcd_group_dealing_ab.txt): off
     int gemm_tile = 0;           // 0 = by M; VSR_GEMM_TILE=64 | 12864 | 128 forces 64x64 / 128x64 / 128x128
     Ctx c;
     // measurement
@@ -517,7 +518,8 @@ struct GemmBuilder {
 int GemmBuilder::launch(hipStream_t s, vsr_handle* h) {
     if (stale_h2) return fail("f16x2 flavour: a GEMM launch names a transposed operand of the training pass that only exists as an fp16-pair image but cannot take an f16x2 kernel (gemm mode / tile override changed since vsr_train_forward, or K / leading dimensions not multiples of 8)");
     if (stale_w) return fail("bf16 mode: a GEMM launch names a transposed operand that only exists as a bf16 image but cannot take the bf16 kernel (K / leading dimensions must be multiples of 8)");
-    dim3 grid(((a.G + 7) / 8) * 8), block((big == 32 || big == 38) ? B16_THREADS : (big == 33 || big == 35 || big == 37) ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34 / 36: 256 = X3S_THREADS = H2S_THREADS)
+    if (!h->xcd_groups) a.xcd_chunk = 0;              // VSR_XCD_GROUPS=0: ceil(G / 8) workgroups per XCD whatever the m-groups (A/B)
+    dim3 grid(gemm_grid(a)), block((big == 32 || big == 38) ? B16_THREADS : (big == 33 || big == 35 || big == 37) ? X3_THREADS : big == 16 ? 512 : 256);       // (big == 34 / 36: 256 = X3S_THREADS = H2S_THREADS)
     const bool prof = h->profiling && (h->prof_seen++ % h->prof_every) == 0 && h->ev_used + 2 <= h->ev.size();
     if (prof) (void)hipEventRecord(h->ev[h->ev_used], s);
     if (big == 36) {
@@ -630,6 +632,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_GEMM_SLOTS")) h->gemm_slots = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_SLOTS_SMALL")) h->gemm_slots_small = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e);
+    if (const char* e = getenv("VSR_XCD_GROUPS")) h->xcd_groups = atoi(e);
     if (const char* e = getenv("VSR_GEMM_MIN_ITERS")) h->gemm_min_iters = std::max(1, atoi(e));
     *out = h;
     return 0;
