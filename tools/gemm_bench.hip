@@ -582,6 +582,42 @@ int main(int argc, char** argv) {
         int ns = b.finish(); double ms = time_it(b, 20);
         printf("S6  nslab %d G %5d  %8.1f us  %6.1f TF/s\n", ns, b.a.G, ms * 1e3, b.flops() / ms / 1e9); tot_ms += ms; tot_fl += b.flops();
     }
+    if (getenv("GEMM_REPACK")) {
+        // round 6: what would other compositions of the step's two wide launches cost?  (all-DMA kernel: run as `GEMM_REPACK=1 tools/gemm_bench 500 256 4 5400 1`)
+        // S5 runs a k-aligned plan on 200 of 256 CUs (64 LSTM2 tiles x 3 pieces + 8 att_ga tiles), S6 stream-K ranges over vocabulary + next LSTM1 sums.
+        auto run = [&](const char* name, bool aligned, auto fill) {
+            if (aligned) setenv("GEMM_PLAN_ALIGNED", "4", 1); else unsetenv("GEMM_PLAN_ALIGNED");
+            Builder b(slots, min_iters, tm, tn);
+            fill(b);
+            int ns = b.finish(); double ms = time_it(b, 20);
+            int T = 0;
+            if (b.a.aligned) for (int i = 0; i < b.a.nprob; ++i) T = std::max(T, (b.a.p[i].ktiles + b.a.p[i].split - 1) / b.a.p[i].split);
+            else T = (b.a.total_iters + b.a.G - 1) / b.a.G;
+            printf("%-58s %s nslab %d G %4d  k-tiles per workgroup %3d  %7.1f us  %6.1f TF/s\n", name, b.a.aligned ? "aligned " : "stream-K", ns, b.a.G, T, ms * 1e3, b.flops() / ms / 1e9);
+            return ms;
+        };
+        auto lstm2 = [&](Builder& b) { GemmProb& p0 = b.prob(M, 4 * H, C, 4 * H);
+            Builder::seg(p0, h1, H, nullptr, Wih2, in2, H); Builder::seg(p0, att, D, nullptr, Wih2 + H, in2, D); Builder::seg(p0, h2, H, pidx, Whh2, H, H); };
+        auto ga = [&](Builder& b) { GemmProb& p1 = b.prob(M, A, C + 8 * (size_t)M * 4 * H, A); Builder::seg(p1, h1, H, nullptr, Wa, H, H); };
+        auto vocab = [&](Builder& b) { GemmProb& p0 = b.prob(M, V, C, V); Builder::seg(p0, h2, H, nullptr, Wout, H, H); };
+        float* C2 = C + 2 * (size_t)M * V;
+        const float* Wi[3] = {Wih1, Wis, Wig}; const float* Wh[3] = {Whh1, Whs, nullptr}; const int N3[3] = {4 * H, H, H}, off3[3] = {0, 4 * H, 5 * H};
+        auto l1 = [&](Builder& b, int i, bool with_h2, bool with_h1) { GemmProb& p = b.prob(M, N3[i], C2 + off3[i], 6 * H);
+            if (with_h2) Builder::seg(p, h2, H, nullptr, Wi[i], in1, H);
+            if (with_h1 && Wh[i]) Builder::seg(p, h1, H, nullptr, Wh[i], H, H); };
+        const double a5 = run("A5 now: LSTM2 | att_ga", true, [&](Builder& b) { lstm2(b); ga(b); });
+        const double a6 = run("A6 now: vocab | gates(h2+h1) | is(h2+h1) | ig(h2)", false, [&](Builder& b) { vocab(b); l1(b, 0, true, true); l1(b, 1, true, true); l1(b, 2, true, false); });
+        const double b5 = run("B5: LSTM2 | gates-h1", true, [&](Builder& b) { lstm2(b); l1(b, 0, false, true); });
+        const double b6 = run("B6: vocab | gates-h2 | is(h2+h1) | ig(h2)   [att_ga omitted]", false, [&](Builder& b) { vocab(b); l1(b, 0, true, false); l1(b, 1, true, true); l1(b, 2, true, false); });
+        const double b6a = run("B6a: the same, k-aligned", true, [&](Builder& b) { vocab(b); l1(b, 0, true, false); l1(b, 1, true, true); l1(b, 2, true, false); });
+        const double c6 = run("C6: vocab | gates-h2 | is-h2 | ig-h2 (uniform K = H)", true, [&](Builder& b) { vocab(b); l1(b, 0, true, false); l1(b, 1, true, false); l1(b, 2, true, false); });
+        const double c5 = run("C5: LSTM2 | gates-h1 | hs-h1", true, [&](Builder& b) { lstm2(b); l1(b, 0, false, true); l1(b, 1, false, true); });
+        const double c5s = run("C5s: the same, stream-K", false, [&](Builder& b) { lstm2(b); l1(b, 0, false, true); l1(b, 1, false, true); });
+        const double d5 = run("D5: LSTM2 | gates-h1 | hs-h1 | att_ga, stream-K", false, [&](Builder& b) { lstm2(b); l1(b, 0, false, true); l1(b, 1, false, true); ga(b); });
+        printf("now A5 + A6 = %.1f us;  B5 + B6 = %.1f us;  B5 + B6a = %.1f us;  C5 + C6 = %.1f us;  C5s + C6 = %.1f us;  D5 + C6 = %.1f us\n",
+               (a5 + a6) * 1e3, (b5 + b6) * 1e3, (b5 + b6a) * 1e3, (c5 + c6) * 1e3, (c5s + c6) * 1e3, (d5 + c6) * 1e3);
+        return 0;
+    }
     if (getenv("GEMM_LONG")) {
         const int KL = 16000, NL_ = 4096;
         float* Al = dev_rand((size_t)M * KL, 31); float* Wl = dev_rand((size_t)NL_ * KL, 32);

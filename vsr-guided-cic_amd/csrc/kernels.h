@@ -371,7 +371,8 @@ __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long str
                         int rpi, const int* __restrict__ parent, const float* __restrict__ c1_old, int M, int H,
                         float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre,
                         const float* __restrict__ xproj, const int* __restrict__ word, int nblk, int pre_by_parent,
-                        uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16 /* optional images (img_store) */, float isc = 0.f) {
+                        uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16 /* optional images (img_store) */, float isc = 0.f,
+                        int skip5 = 0 /* leading slabs that gate block 5 does not have (round 6: the h1 part of the sums comes from the S5 launch, and the shift gate has none) */) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
@@ -384,7 +385,8 @@ __global__ void k_lstm1(const float* __restrict__ pre, int nsplit, long long str
     float q[6];
 #pragma unroll
     for (int g = 0; g < 6; ++g) {
-        float s = g < nblk ? slab_sum(pre + base + (long long)g * H, nsplit, stride) : 0.f;
+        const int sk = g == 5 ? skip5 : 0;
+        float s = g < nblk ? slab_sum(pre + base + (long long)g * H + sk * stride, nsplit - sk, stride) : 0.f;
         if (xp) s += xp[(long long)g * H];
         q[g] = s + vp[(long long)g * H];
     }
@@ -1143,7 +1145,7 @@ __global__ void k_select_simple_lstm1(const SelSimpleArgs sel, const float* __re
                                       const float* __restrict__ vproj, const float* __restrict__ c1_old, int M, int H,
                                       float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t, float* __restrict__ gpre,
                                       const float* __restrict__ xproj, int nblk, uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16,
-                                      float isc) {
+                                      float isc, int skip5) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)M * H) return;
     const int row = (int)(i / H), j = (int)(i % H);
@@ -1152,7 +1154,10 @@ __global__ void k_select_simple_lstm1(const SelSimpleArgs sel, const float* __re
     // the slab sums do not depend on the selection: their loads are in flight while it is made
     float q[6];
 #pragma unroll
-    for (int g = 0; g < 6; ++g) q[g] = g < nblk ? slab_sum(pre + base + (long long)g * H, nsplit, stride) : 0.f;
+    for (int g = 0; g < 6; ++g) {
+        const int sk = g == 5 ? skip5 : 0;
+        q[g] = g < nblk ? slab_sum(pre + base + (long long)g * H + sk * stride, nsplit - sk, stride) : 0.f;
+    }
     const int w = select_simple_row(sel, row, j == 0);
     const float* xp = xproj + (long long)w * 6 * H + j;
 #pragma unroll
@@ -1282,7 +1287,7 @@ __global__ __launch_bounds__((K + 1) * 64) void k_select_lstm1(const SelBeamArgs
                                                                const float* __restrict__ vproj, const float* __restrict__ c1_old, int H, int nslice,
                                                                float* __restrict__ h1n, float* __restrict__ c1n, float* __restrict__ s_t,
                                                                float* __restrict__ gpre, const float* __restrict__ xproj, int nblk,
-                                                               uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16, float isc) {
+                                                               uint16_t* __restrict__ h1n16, uint16_t* __restrict__ s_t16, float isc, int skip5) {
     __shared__ float sums[K * 7 * SL_UB];                  // per parent: six gate sums and its old cell state
     __shared__ int sel_s[2 * KMAX];
     const int b = blockIdx.x / nslice, slice = blockIdx.x % nslice;
@@ -1300,8 +1305,10 @@ __global__ __launch_bounds__((K + 1) * 64) void k_select_lstm1(const SelBeamArgs
             const long long base = (long long)(b * cb + wave) * 6 * H + j;
             const float co = c1_old[(long long)(b * cb + wave) * H + j];
 #pragma unroll
-            for (int g = 0; g < 6; ++g)
-                sums[(wave * 7 + g) * SL_UB + u] = g < nblk ? slab_sum(pre + base + (long long)g * H, nsplit, stride) : 0.f;
+            for (int g = 0; g < 6; ++g) {
+                const int sk = g == 5 ? skip5 : 0;
+                sums[(wave * 7 + g) * SL_UB + u] = g < nblk ? slab_sum(pre + base + (long long)g * H + sk * stride, nsplit - sk, stride) : 0.f;
+            }
             sums[(wave * 7 + 6) * SL_UB + u] = co;
         }
     }

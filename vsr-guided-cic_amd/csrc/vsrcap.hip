@@ -84,7 +84,7 @@ struct Ctx {
     uint16_t *s_t16 = nullptr, *g_t16 = nullptr, *att16 = nullptr;
     bool st16_ok[2] = {false, false};
     float* pre1 = nullptr;       // LSTM1/gate sums of the NEXT step, produced early (merged with the vocabulary GEMM)
-    int pre1_ns = 0, pre1_nblk = 0;
+    int pre1_ns = 0, pre1_nblk = 0, pre1_skip5 = 0;
     long long pre1_stride = 0;
 };
 
@@ -204,6 +204,7 @@ struct vsr_handle {
     int gemm_aligned_min = 8;    // shortest piece, in 64-wide k-tiles (VSR_GEMM_ALIGNED_MIN)
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
     long long rows_bound = 0;    // vsr_set_valid_rows_bound: > 0 = the caller's upper bound on the non-padding region rows; vsr_prepare*() then never waits for the host
+    int split_pre1 = 1;          // the h1 part of the next step's LSTM1 sums in the S5 launch, the h2 part with the vocabulary (run_step; VSR_SPLIT_PRE1=0: all of it with the vocabulary, as in rounds 2-5)
     int xcd_groups = 0;          // VSR_XCD_GROUPS=1: k-aligned plans deal whole m-groups of tiles to an XCD (gemm_plan_aligned).  Measured: 2 % less fabric traffic on the wide kernel, 1.3 % SLOWER end to end (profiles/r06_d_xcd_group_dealing_ab.txt): off
     int gemm_tile = 0;           // 0 = by M; VSR_GEMM_TILE=64 | 12864 | 128 forces 64x64 / 128x64 / 128x128
     Ctx c;
@@ -633,6 +634,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_GEMM_SLOTS_SMALL")) h->gemm_slots_small = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e);
     if (const char* e = getenv("VSR_XCD_GROUPS")) h->xcd_groups = atoi(e);
+    if (const char* e = getenv("VSR_SPLIT_PRE1")) h->split_pre1 = atoi(e);
     if (const char* e = getenv("VSR_GEMM_MIN_ITERS")) h->gemm_min_iters = std::max(1, atoi(e));
     *out = h;
     return 0;
@@ -1189,7 +1191,7 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         const SelBeamArgs& sb = *io.sel_beam;
         const int nslice = cdiv(H, SL_UB);
 #define SELL_LAUNCH(KK) hipLaunchKernelGGL((k_select_lstm1<KK>), dim3(sb.B * nslice), dim3((KK + 1) * 64), 0, s, sb, c.pre1, c.pre1_ns, c.pre1_stride, c.vproj, \
-                                           c1o, H, nslice, h1n, c1n, c.s_t, c.gpre, h->xproj, c.pre1_nblk, h1n16, s_t16, isc); break;
+                                           c1o, H, nslice, h1n, c1n, c.s_t, c.gpre, h->xproj, c.pre1_nblk, h1n16, s_t16, isc, c.pre1_skip5); break;
         switch (sb.beam) {
             case 1: SELL_LAUNCH(1) case 2: SELL_LAUNCH(2) case 3: SELL_LAUNCH(3) case 4: SELL_LAUNCH(4)
             case 5: SELL_LAUNCH(5) case 6: SELL_LAUNCH(6) case 7: SELL_LAUNCH(7) default: SELL_LAUNCH(8)
@@ -1197,10 +1199,10 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
 #undef SELL_LAUNCH
     } else if (io.s1_from_prev && io.sel_simple) {
         hipLaunchKernelGGL(k_select_simple_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, *io.sel_simple, c.pre1, c.pre1_ns, c.pre1_stride,
-                           c.vproj, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, c.pre1_nblk, h1n16, s_t16, isc);
+                           c.vproj, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, c.pre1_nblk, h1n16, s_t16, isc, c.pre1_skip5);
     } else if (io.s1_from_prev) {
         hipLaunchKernelGGL(k_lstm1, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.pre1, c.pre1_ns, c.pre1_stride, c.vproj, io.rpi,
-                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, c.pre1_nblk, 1, h1n16, s_t16, isc);
+                           io.parent, c1o, M, H, h1n, c1n, c.s_t, c.gpre, h->xproj, io.word_prev, c.pre1_nblk, 1, h1n16, s_t16, isc, c.pre1_skip5);
     } else {
         const bool xc = h->xproj != nullptr;            // embedding part comes from the decode cache
         GemmBuilder g;
@@ -1266,13 +1268,54 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         if (io.t > 0) GemmBuilder::seg(p0, h2o, H, io.parent, w.lstm2_weight_hh, H, H, h2o16, H2A_UNIT);
         GemmProb& p1 = g.prob(M, A, nullptr, A);
         GemmBuilder::seg(p1, c.g_t, H, nullptr, w.att_ga_weight, H, H, g_t16, H2A_UNIT);
+        // Round 6 (split_pre1): the h1 part of the NEXT step's LSTM1 / sentinel-gate sums (h1_new . [W_hh1 ; W1_hs]) rides HERE instead
+        // of in the vocabulary launch: S5's k-aligned plan left 56 of 256 CUs idle (64 LSTM2 tiles x 3 pieces + 8 att_ga tiles), and
+        // without these K = H tiles the vocabulary launch is UNIFORM (every tile K = H: one k-aligned piece per tile, no slabs at all).
+        // Measured on the beam-5 shapes (tools/gemm_bench GEMM_REPACK=1, profiles/r06_e_*): 148-153 -> 133 us for the two launches.
+        bool split_pre1 = io.s1_for_next && h->split_pre1 && d.h2_first_lstm;
+        int ns_h1 = 0;
+        auto add_h1 = [&](GemmBuilder& gb) {
+            GemmProb& p2 = gb.prob(M, 4 * H, c.pre1, 6 * H);
+            GemmBuilder::seg(p2, h1n, H, nullptr, w.lstm1_weight_hh, H, H, h1n16, H2A_UNIT);
+            GemmProb& p3 = gb.prob(M, H, c.pre1 + 4 * H, 6 * H);
+            GemmBuilder::seg(p3, h1n, H, nullptr, w.W1_hs_weight, H, H, h1n16, H2A_UNIT);
+        };
+        if (split_pre1) {
+            // both parts land in the 8 slabs of pre1: plan the two launches first and keep the round-5 composition when they would not fit
+            // (the exact-fp32 flavour cuts its 64 x 64 tiles into up to 8 stream-K pieces)
+            GemmBuilder t5 = g, t6;
+            add_h1(t5);
+            t5.finish(h);
+            GemmProb& q0 = t6.prob(M, V, c.scratch, V);
+            GemmBuilder::seg(q0, h2n, H, nullptr, w.out_fc_weight, H, H, h2n16, H2A_UNIT);
+            const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
+            const int Nn[3] = {4 * H, H, H};
+            for (int i = 0; i < 3; ++i) {
+                GemmProb& q = t6.prob(M, Nn[i], c.pre1, 6 * H);
+                GemmBuilder::seg(q, h2n, H, nullptr, Wih[i], in1, H, h2n16, H2A_UNIT);
+            }
+            t6.finish(h);
+            int n6 = 1;
+            for (int i = 1; i < 4; ++i) n6 = std::max(n6, gemm_tight_slabs(t6.a, i));
+            if (std::max(gemm_tight_slabs(t5.a, 2), gemm_tight_slabs(t5.a, 3)) + n6 > 8) split_pre1 = false;
+        }
+        if (split_pre1) add_h1(g);
         const int ns = g.finish(h);
         const long long stride = (long long)M * 4 * H, stride_g = (long long)M * A;
         g.a.p[0].slab_stride = stride;
+        g.a.p[0].nslab = gemm_tight_slabs(g.a, 0);
         g.a.p[1].C = c.ga_slabs; g.a.p[1].slab_stride = stride_g;
         g.a.p[1].nslab = gemm_tight_slabs(g.a, 1);
+        if (split_pre1) {
+            ns_h1 = std::max(gemm_tight_slabs(g.a, 2), gemm_tight_slabs(g.a, 3));
+            g.a.p[2].slab_stride = g.a.p[3].slab_stride = (long long)M * 6 * H;
+            g.a.p[2].nslab = g.a.p[3].nslab = ns_h1;
+        }
+        c.pre1_skip5 = ns_h1;
+        const int ns_lstm2 = g.a.p[0].nslab;
+        if ((size_t)stride * ns > c.scratch_floats) return fail("S5: slabs exceed the workspace scratch");
         if (g.launch(s, h)) return fail("S5 gemm launch failed");
-        hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns, stride, w.lstm2_bias_ih,
+        hipLaunchKernelGGL(k_lstm2, dim3(cdiv((long long)M * H, 256)), dim3(256), 0, s, c.scratch, ns_lstm2, stride, w.lstm2_bias_ih,
                            w.lstm2_bias_hh, d.img_second_lstm ? c.vproj2 : nullptr, io.rpi, io.parent, c2o, M, H, h2n, c2n, h2n16, isc);
         // the gate logits (z_g, log_softmax([z_g, zsum]), step :185-188) are nobody's input before the selection: the
         // vocabulary kernel's row blocks compute them on the side instead of a launch of their own
@@ -1293,11 +1336,12 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
             const float* Wih[3] = {w.lstm1_weight_ih, w.W1_is_weight, w.W1_ig_weight};
             const float* Whh[3] = {w.lstm1_weight_hh, w.W1_hs_weight, nullptr};
             const int Nn[3] = {4 * H, H, H}, off[3] = {0, 4 * H, 5 * H};
+            const bool h1_done = c.pre1_skip5 > 0;         // (split_pre1: the S5 launch above already wrote the h1 part into the leading slabs of pre1)
             for (int i = 0; i < 3; ++i) {
                 if (!d.h2_first_lstm && !Whh[i]) continue;
-                GemmProb& p = g.prob(M, Nn[i], c.pre1 + off[i], 6 * H);
+                GemmProb& p = g.prob(M, Nn[i], c.pre1 + (long long)c.pre1_skip5 * M * 6 * H + off[i], 6 * H);
                 if (d.h2_first_lstm) GemmBuilder::seg(p, h2n, H, nullptr, Wih[i], in1, H, h2n16, H2A_UNIT);
-                if (Whh[i]) GemmBuilder::seg(p, h1n, H, nullptr, Whh[i], H, H, h1n16, H2A_UNIT);
+                if (Whh[i] && !h1_done) GemmBuilder::seg(p, h1n, H, nullptr, Whh[i], H, H, h1n16, H2A_UNIT);
                 nblk = i == 0 ? 4 : i == 1 ? 5 : 6;
             }
         }
@@ -1310,7 +1354,8 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         int ns_pre1 = 1;
         for (int i = 1; i < g.a.nprob; ++i) ns_pre1 = std::max(ns_pre1, gemm_tight_slabs(g.a, i));
         for (int i = 1; i < g.a.nprob; ++i) g.a.p[i].nslab = ns_pre1;
-        c.pre1_ns = g.a.nprob > 1 ? ns_pre1 : ns; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
+        c.pre1_ns = (g.a.nprob > 1 ? ns_pre1 : ns) + c.pre1_skip5; c.pre1_nblk = nblk; c.pre1_stride = (long long)M * 6 * H;
+        if (c.pre1_ns > 8) return fail("S6: the LSTM1 sums of the next step would need %d slabs (8 fit)", c.pre1_ns);
         // the vocabulary tiles (K = H) are cut into fewer pieces than the LSTM1 tiles (K = 2 H) they share the launch with: k_vocab
         // adds only the slabs they wrote (60 -> 40 MB of logits per beam-5 step)
         const int ns_vocab = g.a.p[0].nslab = gemm_tight_slabs(g.a, 0);
