@@ -14,8 +14,6 @@
 // `git show 4789752:tools/ablate/gemm_f32.h` etc.  tools/x3_ablate.py patches scratch copies of the shipped headers instead.
 #define GEMM_ABLATE 0
 #include "../vsr-guided-cic_amd/csrc/gemm_f32.h"
-#include "experiments/gemm_bf16x3.h"
-#include "experiments/gemm_dma_variant.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_bf16.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_x3.h"
 #include "../vsr-guided-cic_amd/csrc/gemm_x3s.h"
@@ -206,10 +204,6 @@ struct Builder {
         else if (tm == 1665) hipLaunchKernelGGL((gemm_nt_bf16w_kernel<true, 2>), g, dim3(B16_THREADS), 0, st, a);
         else if (tm == 2 && tn == 2) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2>), g, b, 0, st, a);
         R16(1) R16(2) R16(3) R16(4) R16(5) R16(6) R16(7) R16(8)
-        else if (tm == 322) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 2, 2, 2>), g, b, 0, st, a);
-        else if (tm == 321) hipLaunchKernelGGL((gemm_nt_bf16x3_kernel<2, 1, 2, 2>), g, b, 0, st, a);
-        else if (tm == 221) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<2, 1, 2, 2>), g, b, 0, st, a);
-        else if (tm == 211) hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<1, 1, 2, 2>), g, b, 0, st, a);
         else if (tm == 112) hipLaunchKernelGGL((gemm_nt_f32_kernel<1, 2, 2, 2>), g, b, 0, st, a);
         else if (tm == 2242) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 2, 4, 2>), g, dim3(512), 0, st, a);
         else if (tm == 2142) hipLaunchKernelGGL((gemm_nt_f32_kernel<2, 1, 4, 2>), g, dim3(512), 0, st, a);

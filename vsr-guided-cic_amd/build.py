@@ -17,7 +17,7 @@ DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HER
 OUT = os.path.join(HERE, "vsrcap", "libvsrcap.so")
 # standalone GEMM check / timing tool (tools/README.md); its `fuzz` mode is run by tests/test_gpu_gemm_fuzz.py
 TOOL_SRC = os.path.join(os.path.dirname(HERE), "tools", "gemm_bench.hip")
-TOOL_DEPS = [TOOL_SRC, os.path.join(os.path.dirname(HERE), "tools", "experiments", "gemm_bf16x3.h"), os.path.join(os.path.dirname(HERE), "tools", "experiments", "gemm_dma_variant.h")] + GEMM_HEADERS
+TOOL_DEPS = [TOOL_SRC] + GEMM_HEADERS
 TOOL_OUT = os.path.join(os.path.dirname(HERE), "tools", "gemm_bench")
 
 
