@@ -80,8 +80,21 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, lon
 __global__ __launch_bounds__(256) void k_row_l1_max(const float* __restrict__ W, const float* __restrict__ bias, int N, int K, unsigned* __restrict__ out) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     float s = 0.f;
-    if (n < N)
-        for (int k = lane; k < K; k += 64) s += fabsf(W[(long long)n * K + k]);
+    if (n < N) {
+        const float* w = W + (long long)n * K;
+        if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
+            // 16 bytes per lane, every load of the row issued before the first use (a refresh runs once per training step: round 6)
+            float4 v[4];
+            for (int k0 = lane * 4; k0 < K; k0 += 1024) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = k0 + 256 * q < K ? *reinterpret_cast<const float4*>(w + k0 + 256 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) s += fabsf(w[k]);
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (n < N && lane == 0) {
@@ -144,7 +157,15 @@ __global__ __launch_bounds__(256) void k_absmax_multi(const H2Multi t, unsigned*
         if (i < t.nt && (int)blockIdx.x >= t.blk[i]) { x = t.src[i]; n = t.n[i]; b0 = t.blk[i]; b1 = t.blk[i + 1]; slot = t.slot[i]; }
     float m = 0.f;
     const long long stride = (long long)(b1 - b0) * 256 * 4;
-    for (long long i = ((long long)(blockIdx.x - b0) * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    long long i = ((long long)(blockIdx.x - b0) * 256 + threadIdx.x) * 4;
+    // four independent 16-byte loads per round (a refresh runs once per training step: round 6)
+    for (; i + 3 * stride + 3 < n; i += 4 * stride) {
+        const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(x + i + stride);
+        const float4 c = *reinterpret_cast<const float4*>(x + i + 2 * stride), d = *reinterpret_cast<const float4*>(x + i + 3 * stride);
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+    }
+    for (; i < n; i += stride) {
         if (i + 3 < n) {
             const float4 v = *reinterpret_cast<const float4*>(x + i);
             m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
