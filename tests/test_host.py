@@ -73,3 +73,66 @@ def test_empty_batch_follows_the_reference():
         m.beam_search((det, ctrl), [3, -1], 3, 1)
     with pytest.raises(RuntimeError):
         m.sample_rl(det, ctrl)
+
+
+def test_weights_generation_moves_with_everything_that_can_move_the_weights():
+    """The derived weight state (fp16-pair images, bf16 copies, decode cache) is keyed on model._weights_version(): it must change on an
+    optimizer step of ANY torch optimizer anywhere (global post-step hook - fused optimizers do not bump Tensor._version), on train() /
+    eval() switches, load_state_dict(), invalidate_cache() and an attached optimizer's step; and stay put otherwise.  (CPU: bookkeeping only.)"""
+    from models import ControllableCaptioningModel
+    m = ControllableCaptioningModel(5, 20, 2, det_feat_size=8, input_encoding_size=8, rnn_size=8, att_size=8, verb_2_vob_all={})
+    v0 = m._weights_version()
+    assert m._weights_version() == v0                        # reading it changes nothing
+    m.eval()
+    v1 = m._weights_version()
+    assert v1 != v0
+    m.eval()
+    assert m._weights_version() == v1                        # no switch, no bump
+    m.train()
+    v2 = m._weights_version()
+    assert v2 != v1
+    # an optimizer that has nothing to do with this model: the process-wide step count still moves (conservative by design)
+    other = torch.nn.Parameter(torch.zeros(3))
+    other.grad = torch.ones(3)
+    torch.optim.SGD([other], lr=0.1).step()
+    v3 = m._weights_version()
+    assert v3 != v2
+    # this model's optimizer
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    v4 = m._weights_version()
+    assert v4 != v3
+    m.load_state_dict(m.state_dict())
+    v5 = m._weights_version()
+    assert v5 != v4
+    m.invalidate_cache()
+    assert m._weights_version() != v5
+
+    class Bare:                                              # an "optimizer" without torch's hooks: attach_optimizer has nothing to register
+        pass
+    assert m.attach_optimizer(Bare()) is None
+    h = m.attach_optimizer(opt)
+    v6 = m._weights_version()
+    opt.step()
+    assert m._weights_version()[0] > v6[0]                   # the attached hook bumped the model's own counter
+    h.remove()
+
+
+def test_live_forward_slots_bookkeeping():
+    """vsrcap.engine._Slot: a slot is 'live' while its forward's token is alive and the forward has not been differentiated"""
+    import gc
+    from vsrcap.engine import _Slot, ForwardToken
+    import weakref
+    s = _Slot()
+    assert not s.live()
+    tok = ForwardToken(7)
+    s.token, s.generation, s.differentiated = weakref.ref(tok), 7, False
+    assert s.live()
+    s.differentiated = True
+    assert not s.live()
+    s.differentiated = False
+    del tok
+    gc.collect()
+    assert not s.live()
