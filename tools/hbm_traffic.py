@@ -53,7 +53,9 @@ def main():
         "write_size_kb_per_launch": write_kb,
         "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
         "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B: MI355X_MICROARCH.md HBM section); "
-                      "WRITE_SIZE as read; the counter is fabric-side: Infinity-Cache hits (activation re-reads) are included",
+                      "WRITE_SIZE as read; the counter is fabric-side: Infinity-Cache hits (activation re-reads) are included.  Both statements "
+                      "calibrated on this chip for this kernel's request type (global_load_lds_dwordx4) and for per-XCD re-reads of one buffer: "
+                      "profiles/r06_c_fetch_size_calibration.txt (tools/fetch_calib.hip)",
         "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py " + bench_args,
     }
     with open(out, "w") as fh:

@@ -68,7 +68,7 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
     constexpr int ST_LD = BN;
     static_assert(32 * ST_LD * 4 <= WSTAGE * 2, "staging band must fit one W stage");
     f32x16 acc[TM][TN];
-    auto flush = [&](auto MULT, float* stage) __attribute__((always_inline)) {
+    auto flush = [&](auto MULT, float* stage, bool range_done) __attribute__((always_inline)) {
         const GemmProb& P = args.p[c_prob];
         const float unscale = h2_pow2(-cur_s);
         const int m0 = (c_tile % P.tiles_m) * BM, n0 = (c_tile / P.tiles_m) * BN;
@@ -82,9 +82,10 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
         const int wm = wave / WN, wn = wave % WN;
         wait_loads<0>();
         __syncthreads();                                   // ... for every wave's requests: nothing lands in `stage` from here on
-        if (args.aligned) {
+        if (args.aligned || range_done) {
             // k-aligned plan: this piece is the workgroup's only one, nothing is prefetched behind it, the whole ring is free: stage all 128
             // rows at once - two barriers instead of eight, every thread's stores back to back (the flush is 3 of a skinny launch's 23 us)
+            // (round 6: the same for the LAST piece of a stream-K range - the movers have issued nothing behind it either)
             static_assert(BM * ST_LD * 4 <= NW * STG * 2, "whole-tile staging must fit the ring");
             static_assert(BM % RPP == 0, "the whole-tile flush walks BM / RPP row groups with no remainder handling");
             float* const all = reinterpret_cast<float*>(sW);
@@ -172,7 +173,7 @@ void gemm_nt_h2a_kernel(const GemmArgs args) {
         const bool piece_done = --c_left == 0;
         __syncthreads();
         if (piece_done) {
-            flush(MULT, reinterpret_cast<float*>(sW + ws * STG));
+            flush(MULT, reinterpret_cast<float*>(sW + ws * STG), it >= it1);
             if (it < it1) decode(it);
         }
         ++j;
