@@ -72,35 +72,50 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, lon
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
         if (!(m == m)) m = __int_as_float(0x7f800000);       // a NaN anywhere: treated as an infinite bound (exponent clamps, NaN stays NaN)
-        atomicMax(out, __float_as_uint(m));
+        if (__float_as_uint(m) > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, __float_as_uint(m));      // (the slot only grows: skip the same-address atomic when there is nothing to add)
     }
 }
 
 // max over rows of (sum_k |W[n][k]| + |bias[n]|): a bound on |W x + bias| for |x| <= 1 (the sentinel vector, step :155)
+constexpr int L1MAX_ROWS = 16;                            // rows per workgroup (four per wave): ONE atomic per workgroup - 2 048 same-address atomics were 25 of this kernel's 30 us
 __global__ __launch_bounds__(256) void k_row_l1_max(const float* __restrict__ W, const float* __restrict__ bias, int N, int K, unsigned* __restrict__ out) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    float s = 0.f;
-    if (n < N) {
-        const float* w = W + (long long)n * K;
-        if ((K & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0) {
-            // 16 bytes per lane, every load of the row issued before the first use (a refresh runs once per training step: round 6)
-            float4 v[4];
-            for (int k0 = lane * 4; k0 < K; k0 += 1024) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool vec = (K & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+    float best = 0.f;
+    bool nan = false;
+    for (int q = 0; q < L1MAX_ROWS / 4; ++q) {
+        const int n = blockIdx.x * L1MAX_ROWS + q * 4 + wave;
+        float s = 0.f;
+        if (n < N) {
+            const float* w = W + (long long)n * K;
+            if (vec) {
+                // 16 bytes per lane, every load of a 1 024-element span issued before the first use
+                float4 v[4];
+                for (int k0 = lane * 4; k0 < K; k0 += 1024) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = k0 + 256 * q < K ? *reinterpret_cast<const float4*>(w + k0 + 256 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int u = 0; u < 4; ++u) v[u] = k0 + 256 * u < K ? *reinterpret_cast<const float4*>(w + k0 + 256 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s += (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w));
+                    for (int u = 0; u < 4; ++u) s += (fabsf(v[u].x) + fabsf(v[u].y)) + (fabsf(v[u].z) + fabsf(v[u].w));
+                }
+            } else {
+                for (int k = lane; k < K; k += 64) s += fabsf(w[k]);
             }
-        } else {
-            for (int k = lane; k < K; k += 64) s += fabsf(w[k]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (n < N) {
+            s += bias ? fabsf(bias[n]) : 0.f;
+            nan = nan || !(s == s);
+            best = fmaxf(best, s);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (n < N && lane == 0) {
-        s += bias ? fabsf(bias[n]) : 0.f;
-        if (!(s == s)) s = __int_as_float(0x7f800000);
-        atomicMax(out, __float_as_uint(s));
+    if (nan) best = __int_as_float(0x7f800000);
+    __shared__ float wm[4];
+    if (lane == 0) wm[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+        if (__float_as_uint(m) > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, __float_as_uint(m));      // (the slot only grows: skip the same-address atomic when there is nothing to add)
     }
 }
 
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(256) void k_absmax_multi(const H2Multi t, unsigned*
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
         if (!(m == m)) m = __int_as_float(0x7f800000);
-        atomicMax(bounds + slot, __float_as_uint(m));
+        if (__float_as_uint(m) > __atomic_load_n(bounds + slot, __ATOMIC_RELAXED)) atomicMax(bounds + slot, __float_as_uint(m));
     }
 }
 __global__ __launch_bounds__(256) void k_f32_to_h2_multi(const H2Multi t, uint32_t* __restrict__ img, const int* __restrict__ exps) {

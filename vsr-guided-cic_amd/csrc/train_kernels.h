@@ -42,7 +42,11 @@ __device__ __forceinline__ void block_absmax_to(const float (&m_in)[NV], int* co
         float r = 0.f;
         const int nw = (blockDim.x + 63) >> 6;
         for (int i = 0; i < nw; ++i) r = fmaxf(r, wm[threadIdx.x][i]);
-        if (r > 0.f) atomicMax(bm[threadIdx.x], __float_as_int(r));
+        // the slot only ever grows: a workgroup whose maximum does not exceed what the slot already holds (a relaxed, possibly STALE read -
+        // stale means smaller, so the test errs on the side of the atomic) has nothing to add.  Same-address atomics serialise at ~12 ns each
+        // on this chip (2 048 of them were 25 of k_row_l1_max's 30 us): with ~400 workgroups per launch that was 4-5 us of every backward
+        // pointwise kernel's tail (round 6).
+        if (r > 0.f && __float_as_int(r) > __atomic_load_n(bm[threadIdx.x], __ATOMIC_RELAXED)) atomicMax(bm[threadIdx.x], __float_as_int(r));
     }
 }
 __device__ __forceinline__ void block_absmax_to(float m, int* bm) {

@@ -885,7 +885,7 @@ extern "C" int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes,
     mt.nt = B16_NW + 1;
     hipLaunchKernelGGL(k_absmax_multi, dim3(blocks), dim3(256), 0, s, mt, bounds);
     // |sentinel| = |s_fc s_t + b| <= max_d (sum_j |W_dj| + |b_d|) since |s_t| < 1                                   (step :155)
-    hipLaunchKernelGGL(k_row_l1_max, dim3(cdiv(d.det_feat_size, 4)), dim3(256), 0, s, h->w.s_fc_weight, h->w.s_fc_bias, d.det_feat_size, d.rnn_size, bounds + H2B_SENT);
+    hipLaunchKernelGGL(k_row_l1_max, dim3(cdiv(d.det_feat_size, L1MAX_ROWS)), dim3(256), 0, s, h->w.s_fc_weight, h->w.s_fc_bias, d.det_feat_size, d.rnn_size, bounds + H2B_SENT);
     hipLaunchKernelGGL(k_h2_exps, dim3(1), dim3(64), 0, s, bounds, idx, idx + H2_NSLOT, idx + 2 * H2_NSLOT, (int)H2A_REGION, exps);   // slots 0 .. 15
     h->h2.clear();
     float* out = reinterpret_cast<float*>(base + H2_HEAD);
