@@ -456,7 +456,10 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                                                 const float* __restrict__ w_s, float* __restrict__ att,
                                                 float* __restrict__ zsum, float* __restrict__ alpha_out,
                                                 uint16_t* __restrict__ att16 = nullptr /* optional image of att */,
-                                                const int* __restrict__ att_exp = nullptr) {
+                                                const int* __restrict__ att_exp = nullptr,
+                                                int nparts = 1 /* workgroups per row (round 6): every part redoes the row's slab sums, scores and softmax
+                                                                  (same arithmetic, same values) and forms 1 / nparts of the D columns of the weighted sum -
+                                                                  a launch of <= 128 rows left half the CUs idle while every row waited for ONE CU's ingest */) {
     extern __shared__ float sm[];
     float* hA_s = sm;             // A
     float* sa_s = hA_s + A;       // A   (fused gate2 only)
@@ -464,8 +467,10 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     float* z_s = sent_s + D;      // R + 1  (then alpha)
     float* red = z_s + R + 1;     // 8
     int* ri_s = reinterpret_cast<int*>(red + 8);   // R: row of P / regions behind slot entry r (dense: its own row)
-    const int row = xcd_item(M);
-    if (row < 0) return;
+    const int item = xcd_item(M * nparts);
+    if (item < 0) return;
+    const int row = item / nparts, part = item - row * nparts;
+    const bool first = part == 0;                  // the part that stores what is not split (g_t, hA, alpha, zsum)
     constexpr int NW = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img = row / rpi;
@@ -497,11 +502,13 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                     float4 o;
                     o.x = sigmoidf_(gp.x + s.x) * tanhf(cn.x); o.y = sigmoidf_(gp.y + s.y) * tanhf(cn.y);
                     o.z = sigmoidf_(gp.z + s.z) * tanhf(cn.z); o.w = sigmoidf_(gp.w + s.w) * tanhf(cn.w);
-                    *reinterpret_cast<float4*>(g2.g_t + (long long)row * H + c) = o;
-                    if (g2.g_t16) img_store4(g2.g_t16, (long long)row * H + c, o, g2.isc);
+                    if (first) {
+                        *reinterpret_cast<float4*>(g2.g_t + (long long)row * H + c) = o;
+                        if (g2.g_t16) img_store4(g2.g_t16, (long long)row * H + c, o, g2.isc);
+                    }
                 } else {
                     *reinterpret_cast<float4*>(hA_s + (c - H)) = s;
-                    *reinterpret_cast<float4*>(g2.hA_out + (long long)row * A + (c - H)) = s;
+                    if (first) *reinterpret_cast<float4*>(g2.hA_out + (long long)row * A + (c - H)) = s;
                 }
             }
             for (int cc = tid * 4; cc < D + A; cc += NT * 4) {
@@ -526,11 +533,13 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
                 const float s = slab_sum(g2.c2a + (long long)row * (H + A) + c, g2.nsplit, g2.stride_a);
                 if (c < H) {
                     const float gv = sigmoidf_(g2.gpre[(long long)row * H + c] + s) * tanhf(g2.c1n[(long long)row * H + c]);
-                    g2.g_t[(long long)row * H + c] = gv;
-                    if (g2.g_t16) img_store(g2.g_t16, (long long)row * H + c, gv, g2.isc);
+                    if (first) {
+                        g2.g_t[(long long)row * H + c] = gv;
+                        if (g2.g_t16) img_store(g2.g_t16, (long long)row * H + c, gv, g2.isc);
+                    }
                 } else {
                     hA_s[c - H] = s;
-                    g2.hA_out[(long long)row * A + (c - H)] = s;
+                    if (first) g2.hA_out[(long long)row * A + (c - H)] = s;
                 }
             }
             for (int cc = tid; cc < D + A; cc += NT) {
@@ -627,9 +636,9 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
             const float m = (j == 0) ? m0 : mk[j - 1];
             const float al = ((expf(z_s[j] - mx) / se) * m) / s2;
             z_s[j] = al;
-            if (alpha_out) alpha_out[(long long)row * (R + 1) + j] = al;
+            if (alpha_out && first) alpha_out[(long long)row * (R + 1) + j] = al;
         }
-        if (lane == 0) zsum[row] = zs;
+        if (lane == 0 && first) zsum[row] = zs;
     }
     __syncthreads();
 
@@ -637,7 +646,8 @@ __global__ __launch_bounds__(NT) void k_attend(const Gate2Args g2, const float* 
     // flight per thread (independent loads) so that the 8 KB rows stream instead of paying one L2/HBM latency each.
     const float a0 = z_s[0];
     const float att_isc = att_exp ? __int_as_float((127 + *att_exp) << 23) : 0.f;      // 2^exponent of the attended vector's bound class
-    for (int d = tid * 4; d < D; d += 4 * NT) {
+    const int Dp = D / nparts;                      // (nparts > 1 only when D is a multiple of 4 nparts: run_step)
+    for (int d = part * Dp + tid * 4; d < (part + 1) * Dp; d += 4 * NT) {
         const float4 s = *reinterpret_cast<const float4*>(srow + d);
         float4 acc = make_float4(a0 * s.x, a0 * s.y, a0 * s.z, a0 * s.w);
         int r = 0;

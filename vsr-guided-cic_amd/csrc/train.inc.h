@@ -388,10 +388,11 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
         }
         {
             const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
-            if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx, slot, 0, 1, B, c.L,
-                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha, att16, att_exp);
-            else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx, slot, 0, 1, B, c.L,
-                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha, att16, att_exp);
+            const int np = (h->attend_parts > 1 && B * h->attend_parts <= h->attend_limit && D % (4 * h->attend_parts) == 0) ? h->attend_parts : 1;      // (as in run_step)
+            if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(B * np, 8) * 8), dim3(512), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx, slot, 0, 1, B, c.L,
+                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha, att16, att_exp, np);
+            else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(B * np, 8) * 8), dim3(256), smem, s, Gate2Args{}, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx, slot, 0, 1, B, c.L,
+                               c.R, A, D, w.att_a_weight, w.att_s_weight, att, c.zsum, alpha, att16, att_exp, np);
         }
         {   // S5
             GemmBuilder g;

@@ -204,6 +204,7 @@ struct vsr_handle {
     int gemm_aligned_min = 8;    // shortest piece, in 64-wide k-tiles (VSR_GEMM_ALIGNED_MIN)
     const float* xproj = nullptr;     // decode cache: (V, 6H) projection of the embedding table, valid for the bound weights
     long long rows_bound = 0;    // vsr_set_valid_rows_bound: > 0 = the caller's upper bound on the non-padding region rows; vsr_prepare*() then never waits for the host
+    int attend_parts = 2, attend_limit = 256;        // workgroups per row of k_attend in launches of <= attend_limit / parts rows (VSR_ATTEND_PARTS, VSR_ATTEND_LIMIT)
     int split_pre1 = 1;          // the h1 part of the next step's LSTM1 sums in the S5 launch, the h2 part with the vocabulary (run_step; VSR_SPLIT_PRE1=0: all of it with the vocabulary, as in rounds 2-5)
     int xcd_groups = 0;          // VSR_XCD_GROUPS=1: k-aligned plans deal whole m-groups of tiles to an XCD (gemm_plan_aligned).  Measured: 2 % less fabric traffic on the wide kernel, 1.3 % SLOWER end to end (profiles/r06_d_xcd_group_dealing_ab.txt): off
     int gemm_tile = 0;           // 0 = by M; VSR_GEMM_TILE=64 | 12864 | 128 forces 64x64 / 128x64 / 128x128
@@ -635,6 +636,8 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_GEMM_TILE")) h->gemm_tile = atoi(e);
     if (const char* e = getenv("VSR_XCD_GROUPS")) h->xcd_groups = atoi(e);
     if (const char* e = getenv("VSR_SPLIT_PRE1")) h->split_pre1 = atoi(e);
+    if (const char* e = getenv("VSR_ATTEND_PARTS")) h->attend_parts = std::max(1, atoi(e));
+    if (const char* e = getenv("VSR_ATTEND_LIMIT")) h->attend_limit = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_GEMM_MIN_ITERS")) h->gemm_min_iters = std::max(1, atoi(e));
     *out = h;
     return 0;
@@ -1253,10 +1256,13 @@ static int run_step(vsr_handle* h, const StepIO& io, hipStream_t s) {
         // k_gate2's work (g_t, hA, s_a, sentinel from the S2 slabs) is done by the attention kernel's row blocks themselves
         const Gate2Args g2{c2a, c2b_base, ns, stride_a, stride_b, c.gpre, c1n, w.s_fc_bias, H, c.g_t, c.hA, g_t16, isc};
         const size_t smem = (size_t)(2 * A + D + c.R + 1 + 8 + c.R) * sizeof(float);
-        if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16, att_exp);
-        else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(M, 8) * 8), dim3(256), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
-                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16, att_exp);
+        // launches of <= 128 rows: two workgroups per row (each forms half of the attended vector's columns): every row's ~370 KB then come in
+        // through two CUs' ingest instead of one while the other half of the chip idles (k_attend, nparts; VSR_ATTEND_PARTS=1: off)
+        const int np = (h->attend_parts > 1 && M * h->attend_parts <= h->attend_limit && D % (4 * h->attend_parts) == 0) ? h->attend_parts : 1;
+        if (D >= 2048) hipLaunchKernelGGL(k_attend<512>, dim3(cdiv(M * np, 8) * 8), dim3(512), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16, att_exp, np);
+        else hipLaunchKernelGGL(k_attend<256>, dim3(cdiv(M * np, 8) * 8), dim3(256), smem, s, g2, c.hA, c.sa, c.sent, c.P, c.regions, c.rmask, c.ridx, io.slot,
+                           io.fixed_slot, io.rpi, M, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, c.att, c.zsum, io.alpha_out, att16, att_exp, np);
     }
     // ---- S5
     GateLogitArgs gate_args;
