@@ -178,10 +178,26 @@ static int gemm_to1(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, int
     return gemm_to(h, t, s, M, N, &sg, 1, dst, ldd);
 }
 // deterministic two-stage column sum through the (idle) slab scratch
-static void colsum(TrainCtx& t, hipStream_t s, const float* X, long long ld, int R, int C, float* out) {
+static void colsum(TrainCtx& t, hipStream_t s, const float* X, long long ld, int R, int C, float* out, float* out2 = nullptr) {
     hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), COLSUM_CHUNKS), dim3(256), 0, s, X, ld, R, C, t.scratch);
-    hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(C, 256)), dim3(256), 0, s, t.scratch, C, out);
+    hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(C, 256)), dim3(256), 0, s, t.scratch, C, 0, C, out, out2);
 }
+// up to ZERO_MT buffers zeroed by one launch (sizes in bytes, multiples of 16; pointers 16-byte aligned)
+struct ZeroList {
+    ZeroMulti z; int blocks = 0;
+    ZeroList() { memset(&z, 0, sizeof(z)); }
+    void add(void* p, size_t bytes) {
+        if (!p || bytes == 0) return;
+        z.p[z.nt] = p; z.n16[z.nt] = (long long)(bytes / 16); z.blk[z.nt] = blocks;
+        blocks += (int)std::max<long long>(1, std::min<long long>(2048, (long long)(bytes / 16 + 1023) / 1024));
+        z.blk[++z.nt] = blocks;
+    }
+    int launch(hipStream_t s) {
+        if (z.nt == 0) return 0;
+        hipLaunchKernelGGL(k_zero_multi, dim3(blocks), dim3(256), 0, s, z);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
+};
 // out = in^T (rows optionally gathered through `list`).  A buffer that a GEMM takes as W receives ONLY its image - the registered bf16
 // twin in the bf16 mode, the fp16-pair image of the f16x2 flavour when the backward pass runs on those kernels (h2img) - and the fp32
 // buffer `out` then only lends its address
@@ -295,17 +311,15 @@ extern "C" int vsr_train_forward(vsr_handle* h, const int64_t* word_in, const in
     register_train_images(h, t);                           // the bf16 twins / fp16-pair images of this workspace's transposed operands
     const int TB = T * B;
     const size_t BH = (size_t)B * H;
-    HIPCHK(hipMemsetAsync(t.h1s, 0, BH * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(t.c1s, 0, BH * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(t.h2s, 0, BH * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(t.c2s, 0, BH * sizeof(float), s));
     // f16x2 flavour: fp16-pair images of the A operands (all-DMA kernel); BH elements of 4 bytes per state slot
     const bool im = h->h2_on && !h->bf16_on && h->x3_on && h->h2_aimg && t.h1s16 && (B * H) % 8 == 0;
     const float isc = im ? 32768.f : 0.f;                  // (2^15: the exponent of the unit-bounded class)
     const int* att_exp = im ? h->h2_exps + H2A_ATT : nullptr;
-    if (im) {
-        HIPCHK(hipMemsetAsync(t.h1s16, 0, BH * 2 * sizeof(uint16_t), s));
-        HIPCHK(hipMemsetAsync(t.h2s16, 0, BH * 2 * sizeof(uint16_t), s));
+    {   // the zero states of step 0 (and their images): one launch
+        ZeroList zl;
+        zl.add(t.h1s, BH * sizeof(float)); zl.add(t.c1s, BH * sizeof(float)); zl.add(t.h2s, BH * sizeof(float)); zl.add(t.c2s, BH * sizeof(float));
+        if (im) { zl.add(t.h1s16, BH * 2 * sizeof(uint16_t)); zl.add(t.h2s16, BH * 2 * sizeof(uint16_t)); }
+        if (zl.launch(s)) return fail("vsr_train_forward: zero launch failed");
     }
     hipLaunchKernelGGL(k_train_indices, dim3(cdiv(TB, 256)), dim3(256), 0, s, word_in, slots, T, B, V, c.L, t.word32, t.slot32, t.rows_bt, c.nvalid_dev + 2);
     hipLaunchKernelGGL(k_gather_rows, dim3(cdiv((long long)TB * E, 256)), dim3(256), 0, s, w.embed_weight, t.word32, TB, E, t.x_all);
@@ -536,11 +550,12 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         if (const H2Range* r2 = h2b ? h->map_h2(t.wT_out) : nullptr) HIPCHK(hipMemsetAsync(const_cast<float*>(r2->img), 0, (size_t)H * Vp * sizeof(float), s));
     }
     transpose(h, s, w.out_fc_weight, H, V, H, t.wT_out, Vp, nullptr, h2b);
-    HIPCHK(hipMemsetAsync(t.dP, 0, (size_t)RL * A * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(t.dh1_c, 0, BH * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(t.dh2_c, 0, BH * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(t.dc1_c[0], 0, BH * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(t.dc2_c[0], 0, BH * sizeof(float), s));
+    {   // dP, the carries of the last step: one launch
+        ZeroList zl;
+        zl.add(t.dP, (size_t)RL * A * sizeof(float));
+        zl.add(t.dh1_c, BH * sizeof(float)); zl.add(t.dh2_c, BH * sizeof(float)); zl.add(t.dc1_c[0], BH * sizeof(float)); zl.add(t.dc2_c[0], BH * sizeof(float));
+        if (zl.launch(s)) return fail("vsr_train_backward: zero launch failed");
+    }
     const int NV = c.nvalid, NVp = (int)up4((size_t)NV);     // non-padding region rows: the only ones att_va saw
     // under a caller's row bound (vsr_set_valid_rows_bound) NV is the BOUND and the list's tail [n, NV) repeats its first entry: the two
     // gathers below read those rows as zeros (k_transpose_t's rlimit = the device-side count), so att_va's gradient sums over n rows
@@ -730,8 +745,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         if (gemm_to1(h, t, s, 4 * H, D, Bp, t.tY_dpre2sum, Bp, t.tX_vbar, Bp, G[g_Wih2] + H + D, in2, dslot(DW_dpre2sum))) return 1;
     }
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H, sP2, tyi)) return 1;
-    colsum(t, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2]);
-    HIPCHK(hipMemcpyAsync(G[g_bhh2], G[g_bih2], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    colsum(t, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2], G[g_bhh2]);
     HIPCHK(hipEventRecord(h->bucket_ev[1], s));
     // ---- bucket 2: out_fc and the embedding
     if (gemm_to1(h, t, s, V, H, TBp, t.tY_dlogits, TBp, t.tX_h2, TBp, G[g_Wout], H, dslot(DW_dlogits), tyi)) return 1;
@@ -748,12 +762,12 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     // ---- bucket 3: the recurrent LSTM1 / sentinel-gate weights, all LSTM1 / gate biases, s_fc, att_va
     if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H, tyi ? sY1 : sP1, tyi)) return 1;
     if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H, tyi ? sY1 : sP1, tyi)) return 1;
-    colsum(t, s, t.dpre1, (long long)6 * H, TB, 4 * H, G[g_bih1]);
-    HIPCHK(hipMemcpyAsync(G[g_bhh1], G[g_bih1], (size_t)4 * H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    colsum(t, s, t.dpre1 + 4 * H, (long long)6 * H, TB, H, G[g_bis]);
-    HIPCHK(hipMemcpyAsync(G[g_bhs], G[g_bis], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
-    colsum(t, s, t.dpre1 + 5 * H, (long long)6 * H, TB, H, G[g_big]);
-    HIPCHK(hipMemcpyAsync(G[g_bhg], G[g_big], (size_t)H * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // the six LSTM1 / gate bias gradients are column sums of ONE matrix (dpre1, 6H columns): one partial-sum launch, three finishing launches
+    // that write both members of a pair (same per-column arithmetic as three separate sums: bit-identical)
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv(6 * H, 64), COLSUM_CHUNKS), dim3(256), 0, s, t.dpre1, (long long)6 * H, TB, 6 * H, t.scratch);
+    hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(4 * H, 256)), dim3(256), 0, s, t.scratch, 6 * H, 0, 4 * H, G[g_bih1], G[g_bhh1]);
+    hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(H, 256)), dim3(256), 0, s, t.scratch, 6 * H, 4 * H, H, G[g_bis], G[g_bhs]);
+    hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(H, 256)), dim3(256), 0, s, t.scratch, 6 * H, 5 * H, H, G[g_big], G[g_bhg]);
     if (gemm_to1(h, t, s, D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H, dslot(DW_step + DY_dsent), tyi)) return 1;
     colsum(t, s, t.dsent_all, (long long)D, TB, D, G[g_bsfc]);
     // att_va: dP^T (A, NV) x regions^T (D, NV) over the non-padding rows

@@ -149,12 +149,28 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ X, lon
     if (q == 0 && c < C)
         part[(long long)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void k_colsum_finish(const float* __restrict__ part, int C, float* __restrict__ out) {
+// columns [c0, c0 + C) of a partial table with Cs columns per chunk; out2 (optional): a second copy (the two bias vectors of an LSTM cell /
+// a gate pair receive the same gradient: lstm_cell_N.bias_ih / bias_hh, W1_is.bias / W1_hs.bias, W1_ig.bias / W1_hg.bias)
+__global__ void k_colsum_finish(const float* __restrict__ part, int Cs, int c0, int C, float* __restrict__ out, float* __restrict__ out2 = nullptr) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
-    for (int k = 0; k < COLSUM_CHUNKS; ++k) s += part[(long long)k * C + c];
+    for (int k = 0; k < COLSUM_CHUNKS; ++k) s += part[(long long)k * Cs + c0 + c];
     out[c] = s;
+    if (out2) out2[c] = s;
+}
+
+// several buffers zeroed by ONE launch (a hipMemsetAsync each was a 5-6 us launch of its own: 14 per training step)
+constexpr int ZERO_MT = 8;
+struct ZeroMulti { void* p[ZERO_MT]; long long n16[ZERO_MT]; int blk[ZERO_MT + 1]; int nt; };       // n16: 16-byte units
+__global__ __launch_bounds__(256) void k_zero_multi(const ZeroMulti z) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < ZERO_MT; ++k)
+        if (k < z.nt && (int)blockIdx.x >= z.blk[k]) i = k;
+    float4* p = reinterpret_cast<float4*>(z.p[i]);
+    const long long n = z.n16[i], stride = (long long)(z.blk[i + 1] - z.blk[i]) * 256;
+    for (long long j = (long long)((int)blockIdx.x - z.blk[i]) * 256 + threadIdx.x; j < n; j += stride) p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // gather of embedding rows for all steps: x_all[(t*B+b)] = embed[word_in[b][t]]
