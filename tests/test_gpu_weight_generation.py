@@ -61,9 +61,13 @@ def test_fused_optimizer_trains_like_foreach_and_eval_sees_the_final_weights(opt
     assert abs(lf[1] - lf[0]) > 1e-3 and abs(lf[2] - lf[1]) > 1e-3, "the loss must move: %s" % (lf,)
     np.testing.assert_allclose(lf, le, atol=2e-6, rtol=0)
     mf, me = runs["fused"][0], runs["foreach"][0]
+    # the two runs see bit-identical gradients (the library is deterministic); what differs is the arithmetic of torch's fused and
+    # foreach kernels, and Adam's m / (sqrt(v) + eps) amplifies their last-bit differences on near-zero gradients to ~1e-3 of one
+    # update (observed: 1.0e-7 on weights of 0.09 at lr 5e-4): the bound is 2e-3 of lr per step on top of 1e-6 of the weight scale
+    lr = 5e-4 if opt == "adam" else 2e-3
     for (k, a), (_, b) in zip(mf.named_parameters(), me.named_parameters()):
         scale = b.abs().max().item() + 1e-30
-        assert (a - b).abs().max().item() <= 1e-6 * scale, k
+        assert (a - b).abs().max().item() <= 1e-6 * scale + 3 * 2e-3 * lr, k
     # evaluation after the fused run: derived state of the FINAL weights
     mf.eval()
     fresh = helpers.build_model(cfg, {k: v.detach().cpu().numpy() for k, v in mf.state_dict().items()}, DEV)

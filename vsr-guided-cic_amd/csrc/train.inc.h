@@ -177,6 +177,41 @@ static int gemm_to1(vsr_handle* h, TrainCtx& t, hipStream_t s, int M, int N, int
     SegSpec sg{A, lda, W, ldw, K, a_cls, a_is_image ? reinterpret_cast<const uint16_t*>(A) : nullptr};
     return gemm_to(h, t, s, M, N, &sg, 1, dst, ldd);
 }
+// Up to four INDEPENDENT products (one K segment each) in ONE launch (round 6): the weight-gradient GEMMs of a bucket.  Alone, a
+// 4000 x 1000 gradient is 128 tiles of 63 k-tiles - cut in halves to fill the chip, i.e. two slabs and a reducing launch - and a
+// 1000 x 1000 one 32 tiles cut in eight; two or three of them together are ~256 whole tiles: no slabs, no reduce, one launch.
+struct GProb { int M, N, K; const float* A; int lda; const float* W; int ldw; float* dst; long long ldd; int a_cls; bool a_img; };
+static int gemm_group(vsr_handle* h, TrainCtx& t, hipStream_t s, const GProb* P, int n) {
+    if (n <= 0) return 0;
+    GemmBuilder g;
+    for (int i = 0; i < n; ++i) {
+        GemmProb& p = g.prob(P[i].M, P[i].N, t.scratch, P[i].N);
+        GemmBuilder::seg(p, P[i].A, P[i].lda, nullptr, P[i].W, P[i].ldw, P[i].K, P[i].a_img ? reinterpret_cast<const uint16_t*>(P[i].A) : nullptr, P[i].a_cls);
+        g.a_image_only = g.a_image_only || (P[i].a_img && !h->bf16_on);
+    }
+    const int ns = g.finish(h);
+    for (int i = 0; i < n; ++i)
+        if (P[i].a_img && !h->bf16_on && g.big != 37) return fail("training gemm group: an A operand exists only as an fp16-pair image but the launch did not take the all-DMA kernel");
+    if (ns == 1) {                          // every tile is produced by one workgroup: written in place
+        for (int i = 0; i < n; ++i) { g.a.p[i].C = P[i].dst; g.a.p[i].ldc = (int)P[i].ldd; g.a.p[i].slab_stride = 0; }
+        if (g.launch(s, h)) return fail("training gemm group launch failed");
+        return 0;
+    }
+    size_t off[4], tot = 0;
+    for (int i = 0; i < n; ++i) {
+        g.a.p[i].nslab = gemm_tight_slabs(g.a, i);
+        off[i] = tot;
+        tot += (size_t)P[i].M * P[i].N * g.a.p[i].nslab;
+    }
+    if (tot > t.scratch_floats) return fail("training scratch too small for a gemm group (%zu floats)", tot);
+    for (int i = 0; i < n; ++i) { g.a.p[i].C = t.scratch + off[i]; g.a.p[i].slab_stride = (long long)P[i].M * P[i].N; }
+    if (g.launch(s, h)) return fail("training gemm group launch failed");
+    for (int i = 0; i < n; ++i) {
+        const long long stride = (long long)P[i].M * P[i].N;
+        hipLaunchKernelGGL(k_slab_reduce_2d, dim3(cdiv(stride, 256)), dim3(256), 0, s, t.scratch + off[i], g.a.p[i].nslab, stride, P[i].M, P[i].N, P[i].dst, P[i].ldd);
+    }
+    return 0;
+}
 // deterministic two-stage column sum through the (idle) slab scratch
 static void colsum(TrainCtx& t, hipStream_t s, const float* X, long long ld, int R, int C, float* out, float* out2 = nullptr) {
     hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), COLSUM_CHUNKS), dim3(256), 0, s, X, ld, R, C, t.scratch);
@@ -727,24 +762,38 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     {
         float* Gw[3] = {G[g_Wih1], G[g_Wis], G[g_Wig]};
         const int r0[3] = {0, 4 * H, 5 * H}, nr[3] = {4 * H, H, H};
-        for (int i = 0; i < 3; ++i) {
-            const float* dy = t.tY_dpre1 + (size_t)r0[i] * TBp;
-            const int sa = tyi ? sY1 : (i == 2 ? sQ : sP1);
-            if (d.h2_first_lstm && gemm_to1(h, t, s, nr[i], H, TBp, dy, TBp, t.tX_h2prev, TBp, Gw[i], in1, sa, tyi)) return 1;
-            if (gemm_to1(h, t, s, nr[i], D, Bp, t.tY_dpre1sum + (size_t)r0[i] * Bp, Bp, t.tX_vbar, Bp, Gw[i] + voff, in1, dslot(DW_dpre1sum))) return 1;
-            if (gemm_to1(h, t, s, nr[i], E, TBp, dy, TBp, t.tX_x, TBp, Gw[i] + xoff, in1, sa, tyi)) return 1;
+        auto dy = [&](int i) { return t.tY_dpre1 + (size_t)r0[i] * TBp; };
+        auto sa = [&](int i) { return tyi ? sY1 : (i == 2 ? sQ : sP1); };
+        auto h2part = [&](int i) { return GProb{nr[i], H, TBp, dy(i), TBp, t.tX_h2prev, TBp, Gw[i], in1, sa(i), tyi}; };
+        auto xpart = [&](int i) { return GProb{nr[i], E, TBp, dy(i), TBp, t.tX_x, TBp, Gw[i] + xoff, in1, sa(i), tyi}; };
+        auto vpart = [&](int i) { return GProb{nr[i], D, Bp, t.tY_dpre1sum + (size_t)r0[i] * Bp, Bp, t.tX_vbar, Bp, Gw[i] + voff, in1, dslot(DW_dpre1sum), false}; };
+        // (grouped launches, round 6: the two 4H-row products are 256 whole tiles together; the four H-row ones share a launch; the three
+        // short-K image-constant parts share one)
+        if (d.h2_first_lstm) {
+            const GProb a[2] = {h2part(0), xpart(0)};
+            if (gemm_group(h, t, s, a, 2)) return 1;
+            const GProb b[4] = {h2part(1), xpart(1), h2part(2), xpart(2)};
+            if (gemm_group(h, t, s, b, 4)) return 1;
+        } else {
+            const GProb a[3] = {xpart(0), xpart(1), xpart(2)};
+            if (gemm_group(h, t, s, a, 3)) return 1;
         }
+        const GProb c3[3] = {vpart(0), vpart(1), vpart(2)};
+        if (gemm_group(h, t, s, c3, 3)) return 1;
     }
     HIPCHK(hipEventRecord(h->bucket_ev[0], s));
     // ---- bucket 1: lstm_cell_2
-    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2, sP2, tyi)) return 1;
+    {   // (the attended-vector part is 256 whole tiles on its own; the h1 part and lstm_cell_2.weight_hh are 256 together)
+        const GProb a[2] = {GProb{4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h1, TBp, G[g_Wih2], in2, sP2, tyi},
+                            GProb{4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H, sP2, tyi}};
+        if (gemm_group(h, t, s, a, 2)) return 1;
+    }
     if (gemm_to1(h, t, s, 4 * H, D, TBp, t.tY_dpre2, TBp, t.tX_att, TBp, G[g_Wih2] + H, in2, sP2, tyi)) return 1;
     if (d.img_second_lstm) {
         hipLaunchKernelGGL(k_sum_over_t, dim3(cdiv((long long)B * 4 * H, 256)), dim3(256), 0, s, t.dpre2, T, (long long)B * 4 * H, t.dpre2sum);
         transpose(h, s, t.dpre2sum, 4 * H, B, 4 * H, t.tY_dpre2sum, Bp);
         if (gemm_to1(h, t, s, 4 * H, D, Bp, t.tY_dpre2sum, Bp, t.tX_vbar, Bp, G[g_Wih2] + H + D, in2, dslot(DW_dpre2sum))) return 1;
     }
-    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre2, TBp, t.tX_h2prev, TBp, G[g_Whh2], H, sP2, tyi)) return 1;
     colsum(t, s, t.dpre2, (long long)4 * H, TB, 4 * H, G[g_bih2], G[g_bhh2]);
     HIPCHK(hipEventRecord(h->bucket_ev[1], s));
     // ---- bucket 2: out_fc and the embedding
@@ -760,15 +809,18 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     }
     HIPCHK(hipEventRecord(h->bucket_ev[2], s));
     // ---- bucket 3: the recurrent LSTM1 / sentinel-gate weights, all LSTM1 / gate biases, s_fc, att_va
-    if (gemm_to1(h, t, s, 4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H, tyi ? sY1 : sP1, tyi)) return 1;
-    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H, tyi ? sY1 : sP1, tyi)) return 1;
+    {   // lstm_cell_1.weight_hh, W1_hs and s_fc: 224 whole tiles in one launch
+        const GProb a[3] = {GProb{4 * H, H, TBp, t.tY_dpre1, TBp, t.tX_h1prev, TBp, G[g_Whh1], H, tyi ? sY1 : sP1, tyi},
+                            GProb{H, H, TBp, t.tY_dpre1 + (size_t)4 * H * TBp, TBp, t.tX_h1prev, TBp, G[g_Whs], H, tyi ? sY1 : sP1, tyi},
+                            GProb{D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H, dslot(DW_step + DY_dsent), tyi}};
+        if (gemm_group(h, t, s, a, 3)) return 1;
+    }
     // the six LSTM1 / gate bias gradients are column sums of ONE matrix (dpre1, 6H columns): one partial-sum launch, three finishing launches
     // that write both members of a pair (same per-column arithmetic as three separate sums: bit-identical)
     hipLaunchKernelGGL(k_colsum, dim3(cdiv(6 * H, 64), COLSUM_CHUNKS), dim3(256), 0, s, t.dpre1, (long long)6 * H, TB, 6 * H, t.scratch);
     hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(4 * H, 256)), dim3(256), 0, s, t.scratch, 6 * H, 0, 4 * H, G[g_bih1], G[g_bhh1]);
     hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(H, 256)), dim3(256), 0, s, t.scratch, 6 * H, 4 * H, H, G[g_bis], G[g_bhs]);
     hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(H, 256)), dim3(256), 0, s, t.scratch, 6 * H, 5 * H, H, G[g_big], G[g_bhg]);
-    if (gemm_to1(h, t, s, D, H, TBp, t.tY_dsent, TBp, t.tX_st, TBp, G[g_Wsfc], H, dslot(DW_step + DY_dsent), tyi)) return 1;
     colsum(t, s, t.dsent_all, (long long)D, TB, D, G[g_bsfc]);
     // att_va: dP^T (A, NV) x regions^T (D, NV) over the non-padding rows
     if (NV > 0) {
@@ -778,10 +830,13 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     }
     HIPCHK(hipEventRecord(h->bucket_ev[3], s));
     // ---- bucket 4 (the tail, 3.5 M floats): W1_hg, att_ha, att_sa, att_ga and the three score vectors
-    if (gemm_to1(h, t, s, H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H, tyi ? sY1 : sQ, tyi)) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H, dslot(DW_step + DY_dhA), tyi)) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H, dslot(DW_step + DY_dsa), tyi)) return 1;
-    if (gemm_to1(h, t, s, A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H, dslot(DW_step + DY_dga), tyi)) return 1;
+    {
+        const GProb a[4] = {GProb{H, H, TBp, t.tY_dpre1 + (size_t)5 * H * TBp, TBp, t.tX_h1, TBp, G[g_Whg], H, tyi ? sY1 : sQ, tyi},
+                            GProb{A, H, TBp, t.tY_dhA, TBp, t.tX_h1, TBp, G[g_Wha], H, dslot(DW_step + DY_dhA), tyi},
+                            GProb{A, H, TBp, t.tY_dsa, TBp, t.tX_st, TBp, G[g_Wsa], H, dslot(DW_step + DY_dsa), tyi},
+                            GProb{A, H, TBp, t.tY_dga, TBp, t.tX_gt, TBp, G[g_Wga], H, dslot(DW_step + DY_dga), tyi}};
+        if (gemm_group(h, t, s, a, 4)) return 1;
+    }
     colsum(t, s, t.dwa_rows, (long long)A, TB, A, G[g_wa]);
     colsum(t, s, t.dws_rows, (long long)A, TB, A, G[g_ws]);
     colsum(t, s, t.dwg_rows, (long long)A, TB, A, G[g_wg]);
