@@ -237,11 +237,40 @@ struct ZeroList {
 // twin in the bf16 mode, the fp16-pair image of the f16x2 flavour when the backward pass runs on those kernels (h2img) - and the fp32
 // buffer `out` then only lends its address
 // self_slot >= 0: `out` itself receives the image (an A operand: a transposed gradient, scaled by the bound in that slot of the table)
+// (batch: transposes without a row list may be COLLECTED and launched together - TransBatch::flush - in the order they were added)
+struct TransBatch {
+    TransMulti m; int kind = -1, blocks = 0; const int* exps = nullptr;
+    TransBatch() { memset(&m, 0, sizeof(m)); }
+    void flush(hipStream_t s) {
+        if (m.nt == 0) return;
+        if (kind == 2) hipLaunchKernelGGL((k_transpose_multi<2>), dim3(blocks), dim3(256), 0, s, m, exps);
+        else if (kind == 1) hipLaunchKernelGGL((k_transpose_multi<1>), dim3(blocks), dim3(256), 0, s, m, exps);
+        else hipLaunchKernelGGL((k_transpose_multi<0>), dim3(blocks), dim3(256), 0, s, m, exps);
+        memset(&m, 0, sizeof(m)); kind = -1; blocks = 0;
+    }
+    void add(hipStream_t s, int k, const int* ex, const float* in, long long ld_in, int R, int C, float* out, long long ld_out, uint16_t* img, int slot) {
+        if (m.nt == TR_MT || (m.nt > 0 && k != kind)) flush(s);
+        kind = k; exps = ex;
+        const int i = m.nt++;
+        m.in[i] = in; m.ld_in[i] = ld_in; m.R[i] = R; m.C[i] = C; m.out[i] = out; m.ld_out[i] = ld_out; m.out16[i] = img; m.slot[i] = slot;
+        m.blk[i] = blocks;
+        blocks += cdiv(C, 64) * cdiv(R, 64);
+        m.blk[i + 1] = blocks;
+    }
+};
 static void transpose(vsr_handle* h, hipStream_t s, const float* in, long long ld_in, int R, int C, float* out, long long ld_out,
-                      const int* list = nullptr, bool h2img = false, int self_slot = -1, const int* rlimit = nullptr) {
+                      const int* list = nullptr, bool h2img = false, int self_slot = -1, const int* rlimit = nullptr, TransBatch* tb = nullptr) {
     uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(out)) : nullptr;
     const dim3 grid(cdiv(C, 64), cdiv(R, 64)), block(256);
     const H2Range* r2 = (h2img && !tw) ? h->map_h2(out) : nullptr;
+    if (tb && !list) {
+        if (h2img && !tw && !r2 && self_slot >= 0 && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 31) == 0)
+            tb->add(s, 2, h->h2_exps, in, ld_in, R, C, out, ld_out, reinterpret_cast<uint16_t*>(out), self_slot);
+        else if (r2) tb->add(s, 2, h->h2_exps, in, ld_in, R, C, out, ld_out, reinterpret_cast<uint16_t*>(const_cast<float*>(r2->img + (out - r2->lo))), r2->slot);
+        else if (tw) tb->add(s, 1, nullptr, in, ld_in, R, C, out, ld_out, tw, 0);
+        else tb->add(s, 0, nullptr, in, ld_in, R, C, out, ld_out, nullptr, 0);
+        return;
+    }
     if (h2img && !tw && !r2 && self_slot >= 0 && ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 31) == 0) {
         uint16_t* img = reinterpret_cast<uint16_t*>(out);
         if (list) hipLaunchKernelGGL((k_transpose_t<true, 2>), grid, block, 0, s, in, ld_in, list, R, C, out, ld_out, img, h->h2_exps, self_slot, rlimit);
@@ -565,26 +594,28 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     auto dslot = [&](int i) { return h2b ? H2_DYN0 + i : (int)H2A_NONE; };
     auto dptr = [&](int i) { return h2b ? dyn + i : (int*)nullptr; };
     if (h2b) HIPCHK(hipMemsetAsync(dyn, 0, H2_NDYN * sizeof(int), s));
-    // ---- transposed weights (the optimizer may have changed them since the last call)
-    transpose(h, s, w.lstm1_weight_ih, in1, 4 * H, in1, t.wT_ih1, 4 * H, nullptr, h2b);
-    transpose(h, s, w.W1_is_weight, in1, H, in1, t.wT_is, H, nullptr, h2b);
-    transpose(h, s, w.W1_ig_weight, in1, H, in1, t.wT_ig, H, nullptr, h2b);
-    transpose(h, s, w.lstm1_weight_hh, H, 4 * H, H, t.wT_hh1, 4 * H, nullptr, h2b);
-    transpose(h, s, w.W1_hs_weight, H, H, H, t.wT_hs, H, nullptr, h2b);
-    transpose(h, s, w.lstm2_weight_ih, in2, 4 * H, in2, t.wT_ih2, 4 * H, nullptr, h2b);
-    transpose(h, s, w.lstm2_weight_hh, H, 4 * H, H, t.wT_hh2, 4 * H, nullptr, h2b);
-    transpose(h, s, w.W1_hg_weight, H, H, H, t.wT_hg, H, nullptr, h2b);
-    transpose(h, s, w.att_ha_weight, H, A, H, t.wT_ha, A, nullptr, h2b);
-    transpose(h, s, w.s_fc_weight, H, D, H, t.wT_sfc, D, nullptr, h2b);
-    transpose(h, s, w.att_sa_weight, H, A, H, t.wT_sa, A, nullptr, h2b);
-    transpose(h, s, w.att_ga_weight, H, A, H, t.wT_ga, A, nullptr, h2b);
+    // ---- transposed weights (the optimizer may have changed them since the last call): one batched launch (TransBatch)
+    TransBatch tbw;
+    transpose(h, s, w.lstm1_weight_ih, in1, 4 * H, in1, t.wT_ih1, 4 * H, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.W1_is_weight, in1, H, in1, t.wT_is, H, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.W1_ig_weight, in1, H, in1, t.wT_ig, H, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.lstm1_weight_hh, H, 4 * H, H, t.wT_hh1, 4 * H, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.W1_hs_weight, H, H, H, t.wT_hs, H, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.lstm2_weight_ih, in2, 4 * H, in2, t.wT_ih2, 4 * H, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.lstm2_weight_hh, H, 4 * H, H, t.wT_hh2, 4 * H, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.W1_hg_weight, H, H, H, t.wT_hg, H, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.att_ha_weight, H, A, H, t.wT_ha, A, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.s_fc_weight, H, D, H, t.wT_sfc, D, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.att_sa_weight, H, A, H, t.wT_sa, A, nullptr, h2b, -1, nullptr, &tbw);
+    transpose(h, s, w.att_ga_weight, H, A, H, t.wT_ga, A, nullptr, h2b, -1, nullptr, &tbw);
     const int Vp = (int)up4(V);        // K of the dh2_vocab GEMM must be a multiple of 8: zero-padded columns
     if (Vp != V) {
         HIPCHK(hipMemsetAsync(t.wT_out, 0, (size_t)H * Vp * sizeof(float), s));
         if (uint16_t* tw = h->bf16_on ? const_cast<uint16_t*>(h->map16(t.wT_out)) : nullptr) HIPCHK(hipMemsetAsync(tw, 0, (size_t)H * Vp * sizeof(uint16_t), s));
         if (const H2Range* r2 = h2b ? h->map_h2(t.wT_out) : nullptr) HIPCHK(hipMemsetAsync(const_cast<float*>(r2->img), 0, (size_t)H * Vp * sizeof(float), s));
     }
-    transpose(h, s, w.out_fc_weight, H, V, H, t.wT_out, Vp, nullptr, h2b);
+    transpose(h, s, w.out_fc_weight, H, V, H, t.wT_out, Vp, nullptr, h2b, -1, nullptr, &tbw);
+    tbw.flush(s);
     {   // dP, the carries of the last step: one launch
         ZeroList zl;
         zl.add(t.dP, (size_t)RL * A * sizeof(float));
@@ -713,15 +744,17 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     const float* h1cur = t.h1s + BH;
     const float* h2prev = t.h2s;
     const float* h2cur = t.h2s + BH;
-    transpose(h, s, h2prev, H, TB, H, t.tX_h2prev, TBp, nullptr, h2b);
-    transpose(h, s, t.x_all, E, TB, E, t.tX_x, TBp, nullptr, h2b);
-    transpose(h, s, h1prev, H, TB, H, t.tX_h1prev, TBp, nullptr, h2b);
-    transpose(h, s, h1cur, H, TB, H, t.tX_h1, TBp, nullptr, h2b);
-    transpose(h, s, t.atts, D, TB, D, t.tX_att, TBp, nullptr, h2b);
-    transpose(h, s, t.s_ts, H, TB, H, t.tX_st, TBp, nullptr, h2b);
-    transpose(h, s, t.g_ts, H, TB, H, t.tX_gt, TBp, nullptr, h2b);
-    transpose(h, s, h2cur, H, TB, H, t.tX_h2, TBp, nullptr, h2b);
-    transpose(h, s, c.vbar, D, B, D, t.tX_vbar, Bp, nullptr, h2b);
+    TransBatch tbx, tby;
+    transpose(h, s, h2prev, H, TB, H, t.tX_h2prev, TBp, nullptr, h2b, -1, nullptr, &tbx);
+    transpose(h, s, t.x_all, E, TB, E, t.tX_x, TBp, nullptr, h2b, -1, nullptr, &tbx);
+    transpose(h, s, h1prev, H, TB, H, t.tX_h1prev, TBp, nullptr, h2b, -1, nullptr, &tbx);
+    transpose(h, s, h1cur, H, TB, H, t.tX_h1, TBp, nullptr, h2b, -1, nullptr, &tbx);
+    transpose(h, s, t.atts, D, TB, D, t.tX_att, TBp, nullptr, h2b, -1, nullptr, &tbx);
+    transpose(h, s, t.s_ts, H, TB, H, t.tX_st, TBp, nullptr, h2b, -1, nullptr, &tbx);
+    transpose(h, s, t.g_ts, H, TB, H, t.tX_gt, TBp, nullptr, h2b, -1, nullptr, &tbx);
+    transpose(h, s, h2cur, H, TB, H, t.tX_h2, TBp, nullptr, h2b, -1, nullptr, &tbx);
+    transpose(h, s, c.vbar, D, B, D, t.tX_vbar, Bp, nullptr, h2b, -1, nullptr, &tbx);
+    tbx.flush(s);
     if (NV > 0) transpose(h, s, c.regions, (long long)D, NV, D, t.tX_reg, (long long)NVp, c.vlist, h2b, -1, nv_dev);
     if (h2b) hipLaunchKernelGGL(k_h2_dyn_fold, dim3(1), dim3(64), 0, s, dyn, T);
     const int sP1 = dslot(DW_step + DY_dpre1), sQ = dslot(DW_step + DY_dq), sP2 = dslot(DW_step + DY_dpre2);
@@ -729,13 +762,14 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
     // written as fp16-pair images IN PLACE of the fp32 values and those GEMMs take the all-DMA kernel (tyi: the buffer holds an image)
     const bool tyi = h2b && h->h2_aimg && TBp % 8 == 0 && (reinterpret_cast<uintptr_t>(t.tY_dpre1) & 255) == 0;     // (every buffer of the workspace shares that alignment)
     const int sY1 = dslot(DW_dpre1all);
-    transpose(h, s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp, nullptr, tyi, sY1);
-    transpose(h, s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp, nullptr, tyi, sP2);
-    transpose(h, s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp, nullptr, tyi, dslot(DW_dlogits));
-    transpose(h, s, t.dhA_all, A, TB, A, t.tY_dhA, TBp, nullptr, tyi, dslot(DW_step + DY_dhA));
-    transpose(h, s, t.dsent_all, D, TB, D, t.tY_dsent, TBp, nullptr, tyi, dslot(DW_step + DY_dsent));
-    transpose(h, s, t.dsa_all, A, TB, A, t.tY_dsa, TBp, nullptr, tyi, dslot(DW_step + DY_dsa));
-    transpose(h, s, t.dga_all, A, TB, A, t.tY_dga, TBp, nullptr, tyi, dslot(DW_step + DY_dga));
+    transpose(h, s, t.dpre1, 6 * H, TB, 6 * H, t.tY_dpre1, TBp, nullptr, tyi, sY1, nullptr, &tby);
+    transpose(h, s, t.dpre2, 4 * H, TB, 4 * H, t.tY_dpre2, TBp, nullptr, tyi, sP2, nullptr, &tby);
+    transpose(h, s, t.dlogits, Vp, TB, V, t.tY_dlogits, TBp, nullptr, tyi, dslot(DW_dlogits), nullptr, &tby);
+    transpose(h, s, t.dhA_all, A, TB, A, t.tY_dhA, TBp, nullptr, tyi, dslot(DW_step + DY_dhA), nullptr, &tby);
+    transpose(h, s, t.dsent_all, D, TB, D, t.tY_dsent, TBp, nullptr, tyi, dslot(DW_step + DY_dsent), nullptr, &tby);
+    transpose(h, s, t.dsa_all, A, TB, A, t.tY_dsa, TBp, nullptr, tyi, dslot(DW_step + DY_dsa), nullptr, &tby);
+    transpose(h, s, t.dga_all, A, TB, A, t.tY_dga, TBp, nullptr, tyi, dslot(DW_step + DY_dga), nullptr, &tby);
+    tby.flush(s);
     const float* dP_rows = t.dP;
     if (c.ridx) {
         // index lists: several slot entries of an image name the same bank row; att_va's gradient runs over bank rows, so the

@@ -58,9 +58,9 @@ __device__ __forceinline__ void block_absmax_to(float m, int* bm) {
 // IMG = 2: ONLY the f16x2 flavour's fp16-pair image (kernels.h: img_store, scaled by 2^exps[slot]) is written, to out16 (2-byte units of a
 // 4-byte-per-element buffer) - the W operands of the backward pass's GEMMs when they run on the f16x2 kernels (train.inc.h: transpose()).
 template <bool GATHER, int IMG>
-__global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int R, int C,
-                                                     float* __restrict__ out, long long ld_out, uint16_t* __restrict__ out16,
-                                                     const int* __restrict__ exps = nullptr, int slot = 0, const int* __restrict__ rlimit = nullptr) {
+__device__ __forceinline__ void transpose_tile(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int R, int C,
+                                               float* __restrict__ out, long long ld_out, uint16_t* __restrict__ out16,
+                                               const int* __restrict__ exps, int slot, const int* __restrict__ rlimit, int bx, int by) {
     constexpr bool BF16 = IMG != 0;            // (either image kind: the fp32 buffer is not written)
     // rlimit (device): input rows from *rlimit up are taken as ZERO rows - the row list of a vsr_prepare*() under a caller's row bound is
     // padded to the bound with copies of its first entry (k_pad_row_list), which the weight-gradient reduction must not see
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ i
         isc = h2_pow2(slot >= H2_DYN0 ? h2_exp_of(__int_as_float(ev)) : ev);
     }
     __shared__ float t[64][65];
-    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int c0 = bx * 64, r0 = by * 64;
     const int q = threadIdx.x & 15, p = threadIdx.x >> 4;              // 16 lanes x 4 floats cover 64 columns; 16 rows per pass
     const bool vin = ((ld_in & 3) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
     const bool vout = ((ld_out & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
@@ -121,6 +121,32 @@ __global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ i
             }
         }
     }
+}
+
+template <bool GATHER, int IMG>
+__global__ __launch_bounds__(256) void k_transpose_t(const float* __restrict__ in, long long ld_in, const int* __restrict__ list, int R, int C,
+                                                     float* __restrict__ out, long long ld_out, uint16_t* __restrict__ out16,
+                                                     const int* __restrict__ exps = nullptr, int slot = 0, const int* __restrict__ rlimit = nullptr) {
+    transpose_tile<GATHER, IMG>(in, ld_in, list, R, C, out, ld_out, out16, exps, slot, rlimit, blockIdx.x, blockIdx.y);
+}
+
+// up to TR_MT transposes of one image kind in ONE launch (round 6: the 13 weight transposes at the head of a backward pass and the 9 + 7
+// activation / gradient transposes of its weight-gradient phase were a 5-10 us launch each)
+constexpr int TR_MT = 16;
+struct TransMulti {
+    const float* in[TR_MT]; float* out[TR_MT]; uint16_t* out16[TR_MT];
+    long long ld_in[TR_MT], ld_out[TR_MT];
+    int R[TR_MT], C[TR_MT], slot[TR_MT], blk[TR_MT + 1];
+    int nt;
+};
+template <int IMG>
+__global__ __launch_bounds__(256) void k_transpose_multi(const TransMulti m, const int* __restrict__ exps) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < TR_MT; ++k)
+        if (k < m.nt && (int)blockIdx.x >= m.blk[k]) i = k;
+    const int local = (int)blockIdx.x - m.blk[i], tc = (m.C[i] + 63) / 64;
+    transpose_tile<false, IMG>(m.in[i], m.ld_in[i], nullptr, m.R[i], m.C[i], m.out[i], m.ld_out[i], m.out16[i], exps, m.slot[i], nullptr, local % tc, local / tc);
 }
 
 // dst (rows, w) window with leading dimension ldd  =  sum of nslab compact (rows, w) slabs
