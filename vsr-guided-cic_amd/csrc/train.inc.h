@@ -536,17 +536,38 @@ __global__ __launch_bounds__(256) void k_dlogits_tb(const float* __restrict__ lo
     const int tt = blockIdx.x / B, b = blockIdx.x % B;
     const long long src = ((long long)b * T + tt) * V, dst = (long long)blockIdx.x * Vp;
     const int tid = threadIdx.x;
+    // 16 bytes per lane where the rows allow it (V a multiple of 4: every row of the (B, T, V) tensors starts 16-byte aligned)
+    const bool vec = (V & 3) == 0 && (Vp & 3) == 0 && ((reinterpret_cast<uintptr_t>(logp) | reinterpret_cast<uintptr_t>(dlogp) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
     float s = 0.f;
-    for (int v = tid; v < V; v += 256) s += dlogp[src + v];
+    if (vec) {
+        for (int v = tid * 4; v < V; v += 1024) {
+            const float4 g = *reinterpret_cast<const float4*>(dlogp + src + v);
+            s += (g.x + g.y) + (g.z + g.w);
+        }
+    } else {
+        for (int v = tid; v < V; v += 256) s += dlogp[src + v];
+    }
     s = wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
     const float tot = (red[0] + red[1]) + (red[2] + red[3]);
     float mx = 0.f;
-    for (int v = tid; v < Vp; v += 256) {
-        const float o = v < V ? dlogp[src + v] - expf(logp[src + v]) * tot : 0.f;
-        dlogits[dst + v] = o;
-        mx = fmaxf(mx, fabsf(o));
+    if (vec) {
+        for (int v = tid * 4; v < Vp; v += 1024) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < V) {
+                const float4 g = *reinterpret_cast<const float4*>(dlogp + src + v), l = *reinterpret_cast<const float4*>(logp + src + v);
+                o = make_float4(g.x - expf(l.x) * tot, g.y - expf(l.y) * tot, g.z - expf(l.z) * tot, g.w - expf(l.w) * tot);
+            }
+            *reinterpret_cast<float4*>(dlogits + dst + v) = o;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+    } else {
+        for (int v = tid; v < Vp; v += 256) {
+            const float o = v < V ? dlogp[src + v] - expf(logp[src + v]) * tot : 0.f;
+            dlogits[dst + v] = o;
+            mx = fmaxf(mx, fabsf(o));
+        }
     }
     if (bm) block_absmax_to(mx, bm);
 }
