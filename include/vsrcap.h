@@ -142,7 +142,11 @@ int vsr_set_gemm_mode(vsr_handle* h, int32_t mode);
  * transposed operands of an f16x2 backward pass exist ONLY as images: a launch that names one and cannot take an f16x2 kernel
  * (vsr_set_gemm_mode / a tile override changed in between) fails instead of reading unwritten fp32 buffers.
  * Environment (experiments): VSR_H2_AIMG=0 (no producer-written A images), VSR_H2S_MAX (rows up to which the weight-streaming kernel
- * is used), VSR_ALIGNED_EFF (percent of busy CUs below which a wide launch takes stream-K ranges instead of k-aligned pieces). */
+ * is used), VSR_ALIGNED_EFF (percent of busy CUs below which a wide launch takes stream-K ranges instead of k-aligned pieces);
+ * round 6: VSR_SPLIT_PRE1=0 (the h1 part of the next step's LSTM1 sums back in the vocabulary launch, as in rounds 2-5),
+ * VSR_ATTEND_PARTS=1 (one attention workgroup per row also in launches of <= 128 rows), VSR_XCD_GROUPS=1 (k-aligned plans deal
+ * whole m-groups of tiles to an XCD: measured slower, off).  None of them changes a result beyond fp32 summation order; every
+ * default is the setting the parity suite ran with. */
 size_t vsr_h2_weight_bytes(const vsr_handle* h);
 int vsr_refresh_h2_weights(vsr_handle* h, void* buffer, size_t bytes, void* stream);
 
