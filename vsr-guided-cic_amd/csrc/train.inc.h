@@ -710,15 +710,20 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
         }
         // attention
         {
-            const size_t smem = (size_t)(R1 + 8) * sizeof(float);
             hipLaunchKernelGGL(k_dalpha, dim3(cdiv((long long)B * R1, 4)), dim3(256), 0, s, t.datt, sent, c.regions, c.rmask, c.ridx, slot, B, c.L, c.R, D,
                                t.dalpha);
-            if (A >= 512) hipLaunchKernelGGL(k_attend_bwd<512>, dim3(cdiv(B, 8) * 8), dim3(512), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx,
+            // two workgroups per row in launches of <= 128 rows (as k_attend): half the A columns each, its 512 threads = 256 columns x 2 row groups
+            const int NTb = A >= 512 ? 512 : 256;
+            int np = (h->attend_parts > 1 && B * h->attend_parts <= h->attend_limit && A % h->attend_parts == 0 && D % (4 * h->attend_parts) == 0) ? h->attend_parts : 1;
+            if (np > 1 && (NTb % (A / np) != 0 || NTb / (A / np) < 1 || (A / np) > NTb)) np = 1;
+            const int RG = np > 1 ? NTb / (A / np) : 1;
+            const size_t smem = (size_t)(R1 + 8 + (np > 1 ? (RG - 1) * (A / np) * 2 : 0)) * sizeof(float);
+            if (A >= 512) hipLaunchKernelGGL(k_attend_bwd<512>, dim3(cdiv(B * np, 8) * 8), dim3(512), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx,
                                slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws,
-                               dptr(tt * 8 + DY_dhA), dptr(tt * 8 + DY_dsent), dptr(tt * 8 + DY_dsa));
-            else hipLaunchKernelGGL(k_attend_bwd<256>, dim3(cdiv(B, 8) * 8), dim3(256), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx,
+                               dptr(tt * 8 + DY_dhA), dptr(tt * 8 + DY_dsent), dptr(tt * 8 + DY_dsa), np);
+            else hipLaunchKernelGGL(k_attend_bwd<256>, dim3(cdiv(B * np, 8) * 8), dim3(256), smem, s, t.datt, t.dalpha, t.dzsum, alpha, hA, sa, sent, c.P, c.regions, c.rmask, c.ridx,
                                slot, 0, B, c.L, c.R, A, D, w.att_a_weight, w.att_s_weight, dsent, dsa, dhA, t.dP, dwa, dws,
-                               dptr(tt * 8 + DY_dhA), dptr(tt * 8 + DY_dsent), dptr(tt * 8 + DY_dsa));
+                               dptr(tt * 8 + DY_dhA), dptr(tt * 8 + DY_dsent), dptr(tt * 8 + DY_dsa), np);
         }
         // grouped GEMM 2: [dq | dhA] -> dh1_b ; [dsent | dsa] -> ds_t;  then the sentinel gate and LSTM1 pointwise backward
         {

@@ -396,25 +396,31 @@ __global__ __launch_bounds__(NT) void k_attend_bwd(const float* __restrict__ dat
                                                     int M, int L, int R, int A, int D, const float* __restrict__ w_a,
                                                     const float* __restrict__ w_s, float* __restrict__ dsent, float* __restrict__ dsa,
                                                     float* __restrict__ dhA, float* __restrict__ dP, float* __restrict__ dwa_rows,
-                                                    float* __restrict__ dws_rows, int* bm_dhA, int* bm_dsent, int* bm_dsa) {
+                                                    float* __restrict__ dws_rows, int* bm_dhA, int* bm_dsent, int* bm_dsa,
+                                                    int nparts = 1 /* workgroups per row (round 6, launches of <= 128 rows): part p owns columns [p A / nparts, ..) of the
+                                                                      A-wide outputs and [p D / nparts, ..) of dsent; the NT threads of a part are A / nparts columns x
+                                                                      RG row groups (region rows r = rg, rg + RG, ..): with 256 columns and two groups a thread's chain
+                                                                      is 18 region rows whose loads are all in flight at once instead of five rounds of eight */) {
     extern __shared__ float sm[];
     float* da = sm;                 // R+1: dalpha, then dz
     float* red = sm + R + 1;        // 8
-    const int row = xcd_item(M);
-    if (row < 0) return;            // (whole workgroups)
+    float* part_s = red + 8;        // nparts > 1: (RG - 1) x Ap x 2 partial sums (dh, dwa) of the row groups behind the first
+    const int item = xcd_item(M * nparts);
+    if (item < 0) return;           // (whole workgroups)
+    const int row = item / nparts, part = item - row * nparts;
     float mx[3] = {0.f, 0.f, 0.f};  // max |dhA|, |dsent|, |dsa| of this row (f16x2 bounds)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = slot ? slot[row] : fixed_slot;
     const long long sl = (long long)row * L + k;
     const float* g = datt + (long long)row * D;
-    const float* Xk = X + sl * R * D;
     const float* al = alpha + (long long)row * (R + 1);
     const float* mk = rmask + sl * R;
     // dalpha comes from k_dalpha (one wave per (row, j))
     for (int j = tid; j < R + 1; j += NT) da[j] = dalpha_in[(long long)row * (R + 1) + j];
-    // dsent = alpha_0 * datt
+    // dsent = alpha_0 * datt   (this part's share of the D columns)
     const float a0 = al[0];
-    for (int d = tid * 4; d < D; d += 4 * NT) {
+    const int Dp = D / nparts;
+    for (int d = part * Dp + tid * 4; d < (part + 1) * Dp; d += 4 * NT) {
         const float4 a = *reinterpret_cast<const float4*>(g + d);
         const float4 o = make_float4(a0 * a.x, a0 * a.y, a0 * a.z, a0 * a.w);
         *reinterpret_cast<float4*>(dsent + (long long)row * D + d) = o;
@@ -442,44 +448,93 @@ __global__ __launch_bounds__(NT) void k_attend_bwd(const float* __restrict__ dat
     // du = dz * w * (1 - tanh^2(P + hA)); dP rows, dhA, dsa and the per-row partials of dw_a / dw_s
     const float* Pk = P + sl * R * A;
     float* dPk = dP + sl * R * A;
-    for (int a = tid; a < A; a += NT) {
+    if (nparts == 1) {
+        for (int a = tid; a < A; a += NT) {
+            const float h = hA[(long long)row * A + a];
+            const float wa = w_a[a];
+            float dh = 0.f, dwa = 0.f;
+            // eight region rows per round: their P and dP loads are all in flight before the first tanh (the row loop was one
+            // dependent load -> tanh -> read-modify-write per row: 36 serial L2 round trips)
+            for (int r0 = 0; r0 < R; r0 += 8) {
+                float pv[8], dpv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = r0 + q;
+                    const bool live = r < R && da[r + 1] != 0.f;            // uniform over the workgroup
+                    pv[q] = live ? (ridx ? P[(long long)ridx[sl * R + r] * A + a] : Pk[(long long)r * A + a]) : 0.f;
+                    dpv[q] = live ? dPk[(long long)r * A + a] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = r0 + q;
+                    if (r < R) {
+                        const float dz = da[r + 1];
+                        if (dz != 0.f) {
+                            const float th = tanhf(pv[q] + h);
+                            const float du = dz * wa * (1.f - th * th);
+                            dPk[(long long)r * A + a] = dpv[q] + du;           // a row visits its slots one step at a time: no race
+                            dh += du;
+                            dwa += dz * th;
+                        }
+                    }
+                }
+            }
+            const float ths = tanhf(sa[(long long)row * A + a] + h);
+            const float dus = da[0] * w_s[a] * (1.f - ths * ths);
+            dsa[(long long)row * A + a] = dus;
+            const float dhn = dhA[(long long)row * A + a] + (dh + dus);
+            dhA[(long long)row * A + a] = dhn;
+            mx[0] = fmaxf(mx[0], fabsf(dhn)); mx[2] = fmaxf(mx[2], fabsf(dus));
+            dwa_rows[(long long)row * A + a] = dwa;
+            dws_rows[(long long)row * A + a] = da[0] * ths;
+        }
+    } else {
+        // this part's Ap columns x RG row groups (NT = Ap RG: run_step checks)
+        const int Ap = A / nparts, RG = NT / Ap;
+        const int al_ = tid % Ap, rg = tid / Ap;
+        const int a = part * Ap + al_;
         const float h = hA[(long long)row * A + a];
         const float wa = w_a[a];
         float dh = 0.f, dwa = 0.f;
-        // eight region rows per round: their P and dP loads are all in flight before the first tanh (the row loop was one
-        // dependent load -> tanh -> read-modify-write per row: 36 serial L2 round trips)
-        for (int r0 = 0; r0 < R; r0 += 8) {
-            float pv[8], dpv[8];
+        constexpr int CH = 18;                       // region rows in flight per thread: one round covers R = 36 with two row groups
+        for (int r0 = rg; r0 < R; r0 += CH * RG) {
+            float pv[CH], dpv[CH];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int r = r0 + q;
-                const bool live = r < R && da[r + 1] != 0.f;            // uniform over the workgroup
+            for (int q = 0; q < CH; ++q) {
+                const int r = r0 + q * RG;
+                const bool live = r < R && da[r + 1] != 0.f;
                 pv[q] = live ? (ridx ? P[(long long)ridx[sl * R + r] * A + a] : Pk[(long long)r * A + a]) : 0.f;
                 dpv[q] = live ? dPk[(long long)r * A + a] : 0.f;
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int r = r0 + q;
+            for (int q = 0; q < CH; ++q) {
+                const int r = r0 + q * RG;
                 if (r < R) {
                     const float dz = da[r + 1];
                     if (dz != 0.f) {
                         const float th = tanhf(pv[q] + h);
                         const float du = dz * wa * (1.f - th * th);
-                        dPk[(long long)r * A + a] = dpv[q] + du;           // a row visits its slots one step at a time: no race
+                        dPk[(long long)r * A + a] = dpv[q] + du;
                         dh += du;
                         dwa += dz * th;
                     }
                 }
             }
         }
-        const float ths = tanhf(sa[(long long)row * A + a] + h);
-        const float dus = da[0] * w_s[a] * (1.f - ths * ths);
-        dsa[(long long)row * A + a] = dus;
-        const float dhn = dhA[(long long)row * A + a] + (dh + dus);
-        dhA[(long long)row * A + a] = dhn;
-        mx[0] = fmaxf(mx[0], fabsf(dhn)); mx[2] = fmaxf(mx[2], fabsf(dus));
-        dwa_rows[(long long)row * A + a] = dwa;
-        dws_rows[(long long)row * A + a] = da[0] * ths;
+        // the row groups' partial sums are added in group order by the first group's thread (fixed order: bitwise repeatable)
+        if (rg > 0) { part_s[((rg - 1) * Ap + al_) * 2] = dh; part_s[((rg - 1) * Ap + al_) * 2 + 1] = dwa; }
+        __syncthreads();
+        if (rg == 0) {
+            for (int q = 1; q < RG; ++q) { dh += part_s[((q - 1) * Ap + al_) * 2]; dwa += part_s[((q - 1) * Ap + al_) * 2 + 1]; }
+            const float ths = tanhf(sa[(long long)row * A + a] + h);
+            const float dus = da[0] * w_s[a] * (1.f - ths * ths);
+            dsa[(long long)row * A + a] = dus;
+            const float dhn = dhA[(long long)row * A + a] + (dh + dus);
+            dhA[(long long)row * A + a] = dhn;
+            mx[0] = fmaxf(mx[0], fabsf(dhn)); mx[2] = fmaxf(mx[2], fabsf(dus));
+            dwa_rows[(long long)row * A + a] = dwa;
+            dws_rows[(long long)row * A + a] = da[0] * ths;
+        }
     }
     if (bm_dhA) {
         int* const bb[3] = {bm_dhA, bm_dsent, bm_dsa};
