@@ -676,7 +676,7 @@ extern "C" int vsr_train_backward(vsr_handle* h, const float* grad_logp_words, c
             BwdHeadArgs q;
             q.lg = t.logp_g + (size_t)tt * 2; q.dlg = grad_logp_gates + (size_t)tt * 2; q.lg_stride = (long long)T * 2;
             q.ga = ga; q.hA = hA; q.w_g = w.att_g_weight; q.A = A;
-            q.dga = dga; q.dhA = dhA; q.dzsum = t.dzsum; q.dwg_rows = dwg; q.gblocks = cdiv(B, 4);
+            q.dga = dga; q.dhA = dhA; q.dzsum = t.dzsum; q.dwg_rows = dwg; q.gblocks = B;
             q.s_h1 = t.scratch; q.s_h2 = d.h2_first_lstm ? t.scratch + st3 * ns3 : nullptr; q.nslab3 = ns3; q.stride3 = st3;
             q.dh1_c = t.dh1_c; q.dh2_c = t.dh2_c; q.dh2_voc = t.dh2_voc + (size_t)tt * BH;
             q.dc_next = t.dc2_c[cb]; q.gates2 = g2; q.c2 = c2; q.c2_prev = tt > 0 ? c2p : nullptr;

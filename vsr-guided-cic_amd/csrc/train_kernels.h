@@ -561,15 +561,17 @@ struct BwdHeadArgs {
 };
 __global__ __launch_bounds__(256) void k_bwd_head(const BwdHeadArgs q) {
     if ((int)blockIdx.x < q.gblocks) {
-        const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+        // one WORKGROUP per row (round 6; a wave per row walked the A columns in eight dependent rounds - load, tanh, three stores - while
+        // the elementwise blocks behind it had long finished: ~6 of this kernel's 13.5 us at batch 100)
+        const int row = blockIdx.x;
         float mx = 0.f;
         if (row < q.M) {
-            const int lane = threadIdx.x & 63, A = q.A;
+            const int A = q.A;
             const float l0 = q.lg[row * q.lg_stride], l1 = q.lg[row * q.lg_stride + 1];
             const float g0 = q.dlg[row * q.lg_stride], g1 = q.dlg[row * q.lg_stride + 1];
             const float tot = g0 + g1;
             const float dzg = g0 - expf(l0) * tot, dzs = g1 - expf(l1) * tot;
-            for (int a = lane; a < A; a += 64) {
+            for (int a = threadIdx.x; a < A; a += 256) {
                 const float th = tanhf(q.ga[(long long)row * A + a] + q.hA[(long long)row * A + a]);
                 const float du = dzg * q.w_g[a] * (1.f - th * th);
                 q.dga[(long long)row * A + a] = du;
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(256) void k_bwd_head(const BwdHeadArgs q) {
                 q.dwg_rows[(long long)row * A + a] = dzg * th;    // summed over rows later (k_colsum)
                 mx = fmaxf(mx, fabsf(du));
             }
-            if (lane == 0) q.dzsum[row] = dzs;
+            if (threadIdx.x == 0) q.dzsum[row] = dzs;
         }
         if (q.bm_dga) block_absmax_to(mx, q.bm_dga);
         return;
