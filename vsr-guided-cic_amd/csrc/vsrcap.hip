@@ -125,7 +125,10 @@ struct vsr_handle {
     // (profiles/r04_e_h2s_routing.txt): 80 - greedy (M = 100, then on the 128 x 128 tile) 660 k tokens/s against 632 k at 128, the 13-image shard
     // (M = 65) 2.61 ms either way; 48 - greedy 668 k, the shard 2.75 ms
     int h2s_max = 80, h2s_slots = 512, h2s_min = 8, h2s_ns = 1;
-    int h2_aligned_min = 4;
+    int h2_aligned_min = 4;      // shortest k-aligned piece of the f16x2 kernels, in 32-wide k-tiles (VSR_H2_ALIGNED_MIN) ...
+    int h2_aligned_min_small = 8;   // ... and in launches whose rows fit ONE m-tile (<= 128 rows: greedy decoding, the per-step GEMMs of training; VSR_H2_ALIGNED_MIN_SMALL).
+                                    // Round 6: 8 instead of 4 there - pieces of 4 k-tiles cost more in their flush than in their k loop: XE +2.4 %, greedy +1.1 %
+                                    // (profiles/r06_t_*).  For the wide launches 8 was REJECTED by the flip-rate fixture (one caption of 1 024 flipped in the default flavour).
     // the producers of the decoder's A operands (h1, h2, s_t, g_t, the attended vector) write fp16-pair images next to the fp32 values
     // and launches whose A operands all have one take the all-DMA kernel (gemm_h2a.h); VSR_H2_AIMG=0: in-kernel split of fp32 A only
     double aligned_eff_min = 0.75;    // wide launches: k-aligned pieces when they keep at least this share of the CUs busy, stream-K ranges otherwise (VSR_ALIGNED_EFF, percent)
@@ -421,7 +424,7 @@ struct GemmBuilder {
                 };
                 if (maxM <= 128) {
                     x3_tn = 1;
-                    if (const int ns = gemm_plan_aligned(a, slots, h->h2_aligned_min, 128, 128, H2_BK)) return ns;
+                    if (const int ns = gemm_plan_aligned(a, slots, h->h2_aligned_min_small, 128, 128, H2_BK)) return ns;
                     return gemm_plan(a, slots, 4, 128, 128, H2_BK);
                 }
                 if (h->x3_aligned_wide != 0) {             // (the planner of the f32x3 wide kernel, below)
@@ -616,6 +619,7 @@ extern "C" int vsr_create(const vsr_dims* dims, vsr_handle** out) {
     if (const char* e = getenv("VSR_H2S_MIN")) h->h2s_min = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2S_NS")) h->h2s_ns = atoi(e) == 2 ? 2 : 1;
     if (const char* e = getenv("VSR_H2_ALIGNED_MIN")) h->h2_aligned_min = std::max(1, atoi(e));
+    if (const char* e = getenv("VSR_H2_ALIGNED_MIN_SMALL")) h->h2_aligned_min_small = std::max(1, atoi(e));
     if (const char* e = getenv("VSR_H2_AIMG")) h->h2_aimg = atoi(e) != 0;
     if (const char* e = getenv("VSR_FUSE_SELECT")) h->fuse_select = atoi(e);
     if (const char* e = getenv("VSR_B16_DMA")) h->b16_dma = atoi(e) != 0;
