@@ -331,7 +331,10 @@ def test_prepare_cache_invalidation():
 # ------------------------------------------------------------------ every GEMM kernel variant keeps token parity
 @pytest.mark.parametrize("env", [dict(VSR_GEMM_TILE="64"), dict(VSR_GEMM_TILE="12864"), dict(VSR_GEMM_TILE="128"),
                                  dict(VSR_GEMM_R16_MAX="0"), dict(VSR_GEMM_R16_MAX="256"), dict(VSR_GEMM_R16_MAX="512"),
-                                 dict(VSR_GEMM_SLOTS="384", VSR_GEMM_MIN_ITERS="4")])
+                                 dict(VSR_GEMM_SLOTS="384", VSR_GEMM_MIN_ITERS="4"),
+                                 # round 6: the launch compositions / plans that are NOT the default stay token-exact too
+                                 dict(VSR_SPLIT_PRE1="0"), dict(VSR_ATTEND_PARTS="1"), dict(VSR_XCD_GROUPS="1"),
+                                 dict(VSR_H2_ALIGNED_MIN_SMALL="4")])
 def test_gemm_kernel_variants_keep_token_parity(env, monkeypatch):
     """The tile / kernel overrides read by vsr_create (64x64, 128x64, 128x128 tiles of the 32x32x2 kernel; the rows-16
     16x16x4 kernel up to 0 / 256 / 512 rows; other stream-K grids) change the summation order, never the tokens: greedy on
