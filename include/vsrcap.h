@@ -183,8 +183,10 @@ int vsr_prepare_indexed(vsr_handle* h, const float* det, int32_t n_img, int32_t 
 /* vsr_prepare*() projects only the NON-PADDING region rows (att_va(0) = 0) and needs their number to size that launch: by default the
  * count is read back (the one place where the library waits for the device).  A caller that knows an upper bound - eval_coco.py:222-237
  * builds det_seqs_recons on the host, train.py's loader pads on the host - passes it here (sticky; 0 = back to the read-back): the
- * following vsr_prepare*() calls then never synchronise (the row list is padded to the bound on the device).  Rows beyond the bound get
- * no projection; their number is added to vsr_bad_ids()'s count (as are bad slot indices of the index-list format in this mode). */
+ * following vsr_prepare*() calls then never synchronise (the row list is padded to the bound on the device; the backward pass of training
+ * reads the padding as zero rows).  A bound that is TOO SMALL is a caller error the call itself cannot report (nothing is read back): the
+ * rows beyond it get a ZERO att_va projection (a defined result, not stale workspace contents) and their number is added to
+ * vsr_bad_ids()'s count, as are bad slot indices of the index-list format in this mode - pair a bound with that check when in doubt. */
 int vsr_set_valid_rows_bound(vsr_handle* h, int64_t max_valid_rows);
 /* mask[i] = (sum_d rows[i, :] != 0), the reference's zero-row test (controllable_captioning.py:126,159) */
 int vsr_row_mask(const float* rows, int64_t n_rows, int32_t D, float* mask, void* stream);

@@ -142,8 +142,9 @@ class ControllableCaptioningModel(CaptioningModel):
         """Extension (not in the reference): an upper bound on the rows of the region tensor that are not zero padding - for index lists,
         on the non-zero rows of the feature bank - which a caller that builds its inputs on the host (coco_scripts/eval_coco.py:222-237,
         data/field.py:44-61) has for free.  The decode / training calls then never wait for the device (include/vsrcap.h,
-        vsr_set_valid_rows_bound).  None switches back to the device-side count + read-back.  A bound that is too small is reported by
-        the next input-contract check (rows beyond it would get no att_va projection)."""
+        vsr_set_valid_rows_bound).  None switches back to the device-side count + read-back.  A bound that is too small cannot fail the call
+        (nothing is read back): the rows beyond it get a ZERO att_va projection and are counted - the input-contract check
+        (VSR_CHECK_IDS=1 / engine.check_ids) turns that count into an IndexError; use it when the bound is not known to be safe."""
         self.valid_rows_bound = None if n is None else int(n)
         return self
 
