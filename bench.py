@@ -465,6 +465,10 @@ def train_bench(args, D, torch, dist, synth, steps, warmup):
         batches.append((det, reg,
                         torch.from_numpy(synth.make_captions(c["B"], c["T"], c["V"], seed=seed)[lo:hi]).contiguous().to(dev),
                         torch.from_numpy(synth.make_gate_gts(c["B"], c["T"], seed=seed)[lo:hi]).contiguous().to(dev)))
+    if getattr(args, "rows_bound", False) and not indexed:
+        # the loader pads on the host (data/field.py:44-61), so the number of non-padding region rows is known there: with it vsr_prepare()
+        # never waits for the device (include/vsrcap.h, vsr_set_valid_rows_bound).  An option, not the default line: the reference's loop does not pass it.
+        m.set_valid_rows_bound(max(int((b[1].sum(-1) != 0).sum()) for b in batches))
     step = parallel.DataParallelStep(m, opt, forward_fn=lambda d, cp, sq: m((d,), (cp, sq)),
                                      sample_fn=lambda d, ct: m.sample_rl(d, ct), all_reduce_fn=D.all_reduce_fn(),
                                      exchange_dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
